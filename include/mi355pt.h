@@ -1,0 +1,264 @@
+/*
+ * mi355pt.h -- C ABI of the MI355X (gfx950) path-tracing backend.
+ *
+ * This is the drop-in boundary for ONE path of WeakKnight/PathTracer: the
+ * ray-scene intersection + Monte-Carlo integration loop that the reference runs in
+ * `PathTracer::{Init,Run,Join}` / `RenderWorker::Run` (reference
+ * include/pathtracer.h:29-64, src/pathtracer.cpp:13-110) over the process globals
+ * defined in src/raytracer.cpp:33-65.  The reference has no FFI of its own (all C++,
+ * one process), so every entry point below names the reference code it stands in for.
+ *
+ * Conventions: plain pointers and sizes, caller-owned host buffers, no C++/torch
+ * types, int status returns (0 = MI355PT_OK).  All matrices use the reference's
+ * (cyMatrix) column-major cell order.  All floats are IEEE binary32.
+ */
+#ifndef MI355PT_H_INCLUDED
+#define MI355PT_H_INCLUDED
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---------------------------------------------------------------- status codes */
+#define MI355PT_OK                 0
+#define MI355PT_ERR_INVALID       -1   /* bad argument / malformed scene description   */
+#define MI355PT_ERR_NO_DEVICE     -2   /* no HIP device, or the device is not gfx950   */
+#define MI355PT_ERR_HIP           -3   /* a HIP runtime call failed (see last_error)   */
+#define MI355PT_ERR_UNSUPPORTED   -4   /* scene uses a feature outside this path       */
+#define MI355PT_ERR_TOO_LARGE     -5   /* request exceeds a documented fixed limit     */
+
+/* ---------------------------------------------------------------- constants
+ * Values are the reference's compile-time contract (include/config.h:19,
+ * include/constants.h:11-16, include/render.h:187). */
+#define MI355PT_MAX_BOUNCES_DEFAULT  30        /* IndirectLightBounceCount             */
+#define MI355PT_RR_START_DEFAULT      3        /* roulette when `bounces > 3`          */
+#define MI355PT_BIGFLOAT         1.0e30f
+#define MI355PT_BIAS             0.0001f       /* INTERSECTION_BIAS                    */
+#define MI355PT_MAX_CHAIN            16        /* max scene-graph depth of an object   */
+
+/* object kinds (reference include/objects.h: Plane, Sphere; include/model.h: Model) */
+#define MI355PT_OBJ_NONE   0
+#define MI355PT_OBJ_PLANE  1
+#define MI355PT_OBJ_SPHERE 2   /* reserved: SURVEY section 8(f) "next"                */
+#define MI355PT_OBJ_MODEL  3
+
+/* material kinds (reference include/disneyMaterial.h, include/standardMaterial.h)    */
+#define MI355PT_MTL_DISNEY   0
+#define MI355PT_MTL_STANDARD 1
+
+/* texture kinds (reference include/texture.h: TextureFile 8-bit / float, TextureChecker) */
+#define MI355PT_TEX_RGB8    0
+#define MI355PT_TEX_RGB32F  1
+#define MI355PT_TEX_CHECKER 2
+
+/* ---------------------------------------------------------------- scene description
+ * A flat copy of what the reference keeps in `rootNode`, `camera`, `lightList`,
+ * `environment`, `materials`, `textureList` (src/raytracer.cpp:33-43).            */
+
+/* One scene-graph Node (reference include/node.h:22-211, include/Transformation.h).
+ * Nodes are listed in depth-first pre-order, children in the reference's child order,
+ * so that `parent < own index` and "earlier index wins ties" reproduces TraceNode
+ * (src/raytracer.cpp:189-258).  Node 0 is `rootNode`.                              */
+typedef struct mi355pt_node {
+    float   tm[9];              /* Transformation::tm   (column-major)                 */
+    float   itm[9];             /* Transformation::itm                                 */
+    float   pos[3];             /* Transformation::pos                                 */
+    float   local_to_world[16]; /* Transformation::localToWorld (4x4, column-major)    */
+    int32_t parent;             /* -1 for the root                                     */
+    int32_t object_kind;        /* MI355PT_OBJ_*                                       */
+    int32_t object_index;       /* index into models[] when kind == MODEL, else 0      */
+    int32_t material;           /* Node::GetMaterial() resolved (inherits), -1 = none  */
+    int32_t light;              /* index into lights[] (Node::GetLight()), -1 = none   */
+} mi355pt_node;
+
+/* One pointer-tree BVH node flattened by the adapter (reference include/bvh.h:243-255).
+ * Optional: when a mesh brings none, the library builds the tree itself with the
+ * reference's split decisions (MeshBVHNew::ScanLineSplit, include/bvh.h:381-494).  */
+typedef struct mi355pt_bvh_node {
+    float    bound[6];          /* BVHBound::data: min xyz, max xyz                    */
+    int32_t  left, right;       /* node indices, -1/-1 for a leaf                      */
+    uint32_t face_first;        /* leaf: range in the mesh's bvh_faces[]               */
+    uint32_t face_count;
+} mi355pt_bvh_node;
+
+/* One Mesh (reference include/mesh.h:30-208).                                       */
+typedef struct mi355pt_mesh {
+    const float*    vertices;   /* 3 * num_vertices                                    */
+    const float*    normals;    /* 3 * num_vertices                                    */
+    const float*    uvw;        /* 3 * num_vertices (Mesh::textureCoords)              */
+    const uint32_t* faces;      /* 4 * num_faces: i0,i1,i2,faceId (Face::indices)      */
+    const float*    tangents;   /* 3 * num_faces, indexed by faceId; may be NULL       */
+    const float*    bitangents; /* 3 * num_faces, indexed by faceId; may be NULL       */
+    uint32_t        num_vertices;
+    uint32_t        num_faces;
+    float           aabb[6];    /* Mesh::aabb: min xyz, max xyz                        */
+    const mi355pt_bvh_node* bvh_nodes;  /* optional reference-built tree, root = 0     */
+    const uint32_t* bvh_faces;          /* concatenated BVHNode::faceList              */
+    uint32_t        num_bvh_nodes;
+    uint32_t        num_bvh_faces;
+} mi355pt_mesh;
+
+/* One Model = a run of meshes (reference include/model.h:16-354).                   */
+typedef struct mi355pt_model {
+    int32_t first_mesh;
+    int32_t num_meshes;
+    float   aabb[6];            /* Model::aabb                                         */
+} mi355pt_model;
+
+/* TextureMap (reference include/scene.h:210-248): a Transformation + texture.      */
+typedef struct mi355pt_texmap {
+    float   itm[9];
+    float   pos[3];
+    int32_t texture;            /* index into textures[], -1 = null texture (black)    */
+} mi355pt_texmap;
+
+typedef struct mi355pt_texture {
+    int32_t     kind;           /* MI355PT_TEX_*                                       */
+    int32_t     width, height;
+    const void* data;           /* RGB8: 3*w*h bytes; RGB32F: 3*w*h floats; rows as the
+                                   reference holds them after its vertical flip
+                                   (src/texture.cpp:60)                                */
+    float       color1[3];      /* checker                                             */
+    float       color2[3];
+} mi355pt_texture;
+
+/* MtlDisney / MtlStandard parameters (reference include/disneyMaterial.h:205-217,
+ * include/standardMaterial.h:105-110).  *_map = index into texmaps[], -1 = no map.  */
+typedef struct mi355pt_material {
+    int32_t kind;               /* MI355PT_MTL_*                                       */
+    float   albedo[3];
+    float   roughness[3];
+    float   metalness[3];
+    int32_t albedo_map, roughness_map, metalness_map, normal_map;
+    float   specular, specular_tint, sheen, sheen_tint;
+    float   clearcoat, clearcoat_gloss, subsurface;
+} mi355pt_material;
+
+/* LightComponent (reference include/lightcomponent.h:8-20).                         */
+typedef struct mi355pt_light {
+    int32_t node;               /* LightComponent::parent                              */
+    float   intensity[3];
+} mi355pt_light;
+
+/* Camera after LoadScene (reference include/scene.h:313-331, src/xmlload.cpp:119-137):
+ * `dir` normalised, `up` re-orthogonalised.                                          */
+typedef struct mi355pt_camera {
+    float   pos[3], dir[3], up[3];
+    float   fov, focaldist, dof;
+    int32_t width, height;
+} mi355pt_camera;
+
+typedef struct mi355pt_scene_desc {
+    const mi355pt_node*     nodes;      uint32_t num_nodes;
+    const mi355pt_model*    models;     uint32_t num_models;
+    const mi355pt_mesh*     meshes;     uint32_t num_meshes;
+    const mi355pt_material* materials;  uint32_t num_materials;
+    const mi355pt_texmap*   texmaps;    uint32_t num_texmaps;
+    const mi355pt_texture*  textures;   uint32_t num_textures;
+    const mi355pt_light*    lights;     uint32_t num_lights;
+    float                   env_color[3];   /* `environment` colour (scene.h:262)      */
+    int32_t                 env_map;        /* texmap index or -1                      */
+    mi355pt_camera          camera;
+} mi355pt_scene_desc;
+
+/* Render parameters.  The reference hard-codes these (include/config.h) or takes them
+ * from the camera; `seed` keys the counter-based stand-in for libc rand().          */
+typedef struct mi355pt_render_params {
+    uint32_t width, height;     /* PathTracer::Init(w,h)                               */
+    uint32_t max_bounces;       /* 30                                                  */
+    uint32_t rr_start;          /* 3                                                   */
+    uint32_t seed;
+    uint32_t sample_offset;     /* first sample index this renderer owns (multi-GPU)   */
+    uint32_t sample_stride;     /* sample index stride (1 on one GPU, G on G GPUs)     */
+    int32_t  device;            /* HIP device ordinal                                  */
+} mi355pt_render_params;
+
+/* Per-renderer counters (SURVEY section 8d ray-counting rule: 1 per TraceNode call,
+ * 1 per LightVisTest call).                                                          */
+typedef struct mi355pt_stats {
+    uint64_t closest_rays;      /* TraceNode calls                                     */
+    uint64_t shadow_rays;       /* LightVisTest calls                                  */
+    uint64_t samples;           /* RenderPixel calls                                   */
+    uint64_t bvh_node_visits;   /* internal-node records fetched (counting builds)     */
+    uint64_t bvh_tri_tests;     /* triangle records fetched (counting builds)          */
+    double   extend_ms;         /* device time in the closest-hit kernel (HIP events)  */
+    double   shade_ms;
+    double   connect_ms;
+    double   other_ms;
+    uint64_t extend_launches;
+} mi355pt_stats;
+
+typedef struct mi355pt_scene  mi355pt_scene;    /* opaque: flattened scene in HBM      */
+typedef struct mi355pt_render mi355pt_render;   /* opaque: accumulator + path queues   */
+
+/* Library / device. */
+const char* mi355pt_version(void);
+const char* mi355pt_last_error(void);
+/* Number of usable gfx950 devices (0 when none): there is NO CPU fallback. */
+int mi355pt_device_count(void);
+
+/* Replaces: the scene globals a `PathTracer` reads (src/raytracer.cpp:33-45) plus
+ * `Mesh::BuildBVH` (src/mesh.cpp:6-14) when a mesh brings no tree.  Copies the
+ * description, flattens it to the SoA layout of DESIGN.md and uploads it.          */
+int mi355pt_scene_create(const mi355pt_scene_desc* desc, int32_t device, mi355pt_scene** out);
+void mi355pt_scene_destroy(mi355pt_scene* scene);
+
+/* Export of the BVH the library holds for `mesh` in the reference's pointer-tree
+ * form, for node-for-node comparison with MeshBVHNew (include/bvh.h:257-530).
+ * Call with nodes == NULL to query sizes.                                           */
+int mi355pt_scene_get_bvh(const mi355pt_scene* scene, uint32_t mesh,
+                          mi355pt_bvh_node* nodes, uint32_t* num_nodes,
+                          uint32_t* faces, uint32_t* num_faces);
+
+/* Replaces: PathTracer::Init (src/pathtracer.cpp:13-21) -- allocates the per-pixel
+ * PixelContext state (running mean, sample count, Cranley-Patterson offset).       */
+int mi355pt_render_create(mi355pt_scene* scene, const mi355pt_render_params* params,
+                          mi355pt_render** out);
+void mi355pt_render_destroy(mi355pt_render* render);
+
+/* Replaces: one pass of every RenderWorker over all pixels, `spp` times
+ * (src/pathtracer.cpp:66-109): SamplePixel -> RenderPixel -> running mean -> RGB8.
+ * Asynchronous on the renderer's stream; `mi355pt_render_sync` waits.              */
+int mi355pt_render_step(mi355pt_render* render, uint32_t spp);
+int mi355pt_render_sync(mi355pt_render* render);
+
+/* Replaces: renderImage.GetPixels() as the GUI reads it (src/raytracer.cpp:449):
+ * Color24[w*h], row-major, y = 0 at the top, uint8(mean*255) truncating.           */
+int mi355pt_render_read_rgb8(mi355pt_render* render, uint8_t* rgb);
+/* PixelContext::color / CurrentSampleNum (include/pathtracer.h:13-27): float mean
+ * RGB (3*w*h) and per-pixel sample counts (w*h); either pointer may be NULL.       */
+int mi355pt_render_read_accum(mi355pt_render* render, float* mean_rgb, uint32_t* count);
+/* Restore / merge an accumulator (checkpoint-resume, multi-GPU combine).           */
+int mi355pt_render_write_accum(mi355pt_render* render, const float* mean_rgb, const uint32_t* count);
+/* Device pointers of the accumulator (float RGB mean, u32 counts) for zero-copy
+ * RCCL reduction by the caller; valid until render_destroy.                        */
+int mi355pt_render_accum_device_ptrs(mi355pt_render* render, void** mean_rgb, void** count);
+
+/* Parity hooks (no reference counterpart as API; they expose intermediate values of
+ * the functions named):
+ *  - trace_primary: TraceNode (src/raytracer.cpp:189-258) on the un-jittered camera
+ *    ray context of every pixel in [x0,x1) x [y0,y1) (SamplePixel with offset 0 ->
+ *    GenCameraRayContext(x,y,0,0), dof draws taken from sample index 0).  Outputs per
+ *    pixel: node index, mesh index within the model, face id, t (BIGFLOAT on a miss;
+ *    ids -1).
+ *  - sample_radiance: RenderPixel (include/render.h:107-246) for explicit
+ *    (pixel index, sample index) pairs; writes the linear colour before ACES (3
+ *    floats) and the tone-mapped, gamma-corrected sample colour (3 floats).        */
+int mi355pt_trace_primary(mi355pt_render* render, uint32_t x0, uint32_t y0, uint32_t x1, uint32_t y1,
+                          int32_t* node, int32_t* mesh, int32_t* face, float* t);
+int mi355pt_sample_radiance(mi355pt_render* render, const uint32_t* pixel, const uint32_t* sample,
+                            uint32_t count, float* linear_rgb, float* mapped_rgb);
+
+int mi355pt_render_stats(mi355pt_render* render, mi355pt_stats* stats);
+int mi355pt_render_reset_stats(mi355pt_render* render);
+
+/* The stream (hipStream_t) the renderer launches on, for callers that time kernels
+ * with their own HIP events.                                                        */
+void* mi355pt_render_stream(mi355pt_render* render);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MI355PT_H_INCLUDED */
