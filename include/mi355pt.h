@@ -212,6 +212,14 @@ int mi355pt_scene_get_bvh(const mi355pt_scene* scene, uint32_t mesh,
                           mi355pt_bvh_node* nodes, uint32_t* num_nodes,
                           uint32_t* faces, uint32_t* num_faces);
 
+/* Replaces: Mesh::BuildBVH -> MeshBVHNew (reference src/mesh.cpp:6-14, include/bvh.h:257-530).
+ * Host-only (no device needed): builds the tree for one mesh and returns it in the reference's
+ * pointer-tree form, nodes in creation order (node, left subtree, right subtree).  Call with
+ * nodes == NULL to query sizes.                                                               */
+int mi355pt_build_bvh(const float* vertices, uint32_t num_vertices, const uint32_t* faces, uint32_t num_faces,
+                      const float aabb[6], mi355pt_bvh_node* nodes, uint32_t* num_nodes,
+                      uint32_t* bvh_faces, uint32_t* num_bvh_faces);
+
 /* Replaces: PathTracer::Init (src/pathtracer.cpp:13-21) -- allocates the per-pixel
  * PixelContext state (running mean, sample count, Cranley-Patterson offset).       */
 int mi355pt_render_create(mi355pt_scene* scene, const mi355pt_render_params* params,
@@ -253,6 +261,11 @@ int mi355pt_sample_radiance(mi355pt_render* render, const uint32_t* pixel, const
 
 int mi355pt_render_stats(mi355pt_render* render, mi355pt_stats* stats);
 int mi355pt_render_reset_stats(mi355pt_render* render);
+
+/* Measurement switches (no reference counterpart): enable_events brackets every kernel launch
+ * with HIP events on the renderer's stream (summed into mi355pt_stats.*_ms at the next sync);
+ * count_work selects the kernel builds that count BVH node records and triangle records fetched. */
+int mi355pt_render_set_profiling(mi355pt_render* render, int enable_events, int count_work);
 
 /* The stream (hipStream_t) the renderer launches on, for callers that time kernels
  * with their own HIP events.                                                        */

@@ -95,11 +95,11 @@ def make_params(width, height, seed=0x5EED, max_bounces=30, rr_start=3, sample_o
 # Every symbol include/mi355pt.h declares (checked by tests/test_abi.py).
 SYMBOLS = [
     "mi355pt_version", "mi355pt_last_error", "mi355pt_device_count",
-    "mi355pt_scene_create", "mi355pt_scene_destroy", "mi355pt_scene_get_bvh",
+    "mi355pt_scene_create", "mi355pt_scene_destroy", "mi355pt_scene_get_bvh", "mi355pt_build_bvh",
     "mi355pt_render_create", "mi355pt_render_destroy", "mi355pt_render_step", "mi355pt_render_sync",
     "mi355pt_render_read_rgb8", "mi355pt_render_read_accum", "mi355pt_render_write_accum",
     "mi355pt_render_accum_device_ptrs", "mi355pt_trace_primary", "mi355pt_sample_radiance",
-    "mi355pt_render_stats", "mi355pt_render_reset_stats", "mi355pt_render_stream",
+    "mi355pt_render_stats", "mi355pt_render_reset_stats", "mi355pt_render_set_profiling", "mi355pt_render_stream",
 ]
 
 _lib = None
@@ -124,6 +124,8 @@ def load_library(path=None):
     lib.mi355pt_scene_destroy.argtypes = [vp]
     lib.mi355pt_scene_destroy.restype = None
     lib.mi355pt_scene_get_bvh.argtypes = [vp, u32, C.POINTER(BvhNode), C.POINTER(u32), C.POINTER(u32), C.POINTER(u32)]
+    lib.mi355pt_build_bvh.argtypes = [C.c_void_p, u32, C.c_void_p, u32, C.POINTER(f32), C.POINTER(BvhNode), C.POINTER(u32),
+                                      C.c_void_p, C.POINTER(u32)]
     lib.mi355pt_render_create.argtypes = [vp, C.POINTER(RenderParams), C.POINTER(vp)]
     lib.mi355pt_render_destroy.argtypes = [vp]
     lib.mi355pt_render_destroy.restype = None
@@ -137,6 +139,7 @@ def load_library(path=None):
     lib.mi355pt_sample_radiance.argtypes = [vp, C.c_void_p, C.c_void_p, u32, C.c_void_p, C.c_void_p]
     lib.mi355pt_render_stats.argtypes = [vp, C.POINTER(Stats)]
     lib.mi355pt_render_reset_stats.argtypes = [vp]
+    lib.mi355pt_render_set_profiling.argtypes = [vp, C.c_int, C.c_int]
     lib.mi355pt_render_stream.argtypes = [vp]
     lib.mi355pt_render_stream.restype = vp
     if path is None:
@@ -152,3 +155,17 @@ def check(lib, status, what):
     if status != OK:
         err = lib.mi355pt_last_error()
         raise BackendError(f"{what} failed with status {status}: {err.decode() if err else ''}")
+
+
+def build_bvh(mesh):
+    """mi355pt_build_bvh for a scene.Mesh -> (BvhNode array, face list)."""
+    import numpy as np
+    lib = load_library()
+    nn, nf = u32(0), u32(0)
+    aabb = (f32 * 6)(*mesh.aabb.tolist())
+    args = (mesh.vertices.ctypes.data, mesh.vertices.shape[0], mesh.faces.ctypes.data, mesh.faces.shape[0], aabb)
+    check(lib, lib.mi355pt_build_bvh(*args, None, C.byref(nn), None, C.byref(nf)), "mi355pt_build_bvh")
+    nodes = (BvhNode * max(1, nn.value))()
+    faces = np.zeros(max(1, nf.value), dtype=np.uint32)
+    check(lib, lib.mi355pt_build_bvh(*args, nodes, C.byref(nn), faces.ctypes.data, C.byref(nf)), "mi355pt_build_bvh")
+    return nodes, faces[:nf.value], nn.value

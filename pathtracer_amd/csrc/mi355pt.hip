@@ -1,0 +1,887 @@
+// mi355pt.hip -- wavefront path-tracing kernels for gfx950 and the C ABI of include/mi355pt.h.
+//
+// One render_step = for each chunk of (pixel, sample) paths:
+//   init -> { extend -> shade -> connect } x max_bounces -> resolve
+// with index queues compacted by wave64 ballot + one atomic per wave, kernel grids that read
+// their work count from device memory (no host round trip inside a step), and a per-pixel
+// running mean that reproduces RenderWorker::Run (reference src/pathtracer.cpp:66-109).
+// Kernel <-> reference function map: DESIGN.md "Kernels".
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/mi355pt.h"
+#include "bvh_build.h"
+#include "pt_device.h"
+#include "pt_scene.h"
+#include "pt_shade.h"
+
+using namespace ptd;
+
+// ====================================================================== path state
+constexpr int kShFields = 26;
+enum ShField { SH_OX = 0, SH_OY, SH_OZ, SH_W1X, SH_W1Y, SH_W1Z, SH_TMAX1, SH_C1X, SH_C1Y, SH_C1Z,
+               SH_W2X, SH_W2Y, SH_W2Z, SH_A2X, SH_A2Y, SH_A2Z, SH_PDFB, SH_HPX, SH_HPY, SH_HPZ,
+               SH_TBX, SH_TBY, SH_TBZ, SH_SELPDF, SH_FLAGS, SH_LIGHT };
+
+struct DPaths {
+    uint32_t  cap;
+    uint32_t *pix, *smp, *draw;
+    float    *ray;        // 6 x cap : origin, direction of the ray to trace next (bounce > 0)
+    float    *T, *C;      // 3 x cap each: throughput, accumulated radiance
+    float    *ht; int *hinst, *hmesh; uint32_t *hslot;       // closest-hit record
+    float    *sh;         // kShFields x cap: NEE / MIS shadow work of the current bounce
+    uint32_t *queue[2];   // path-slot indices, ping-pong
+    uint32_t *squeue;     // slots with shadow work this bounce
+    uint32_t *counts;     // [b] = #paths entering bounce b (b >= 1)
+    uint32_t *scounts;    // [b] = #paths with shadow work at bounce b
+    unsigned long long *stat;   // [0] closest rays [1] shadow rays [2] samples [3] node visits [4] tri tests
+};
+struct Params { uint32_t seed, width, height, max_bounces, rr_start; };
+
+#define PT_LD3(arr, cap, i) f3((arr)[(i)], (arr)[(size_t)(cap) + (i)], (arr)[2 * (size_t)(cap) + (i)])
+#define PT_ST3(arr, cap, i, v) do { (arr)[(i)] = (v).x; (arr)[(size_t)(cap) + (i)] = (v).y; (arr)[2 * (size_t)(cap) + (i)] = (v).z; } while (0)
+
+constexpr int kBlock = 256;
+
+// wave64 compaction: one atomic per wave (ballot + mbcnt prefix)
+__device__ __forceinline__ void wave_enqueue(bool pred, uint32_t value, uint32_t* queue, uint32_t* counter) {
+    const unsigned long long mask = __ballot(pred);
+    if (mask == 0) return;
+    const int lane = __lane_id();
+    const int leader = __ffsll((long long)mask) - 1;
+    uint32_t base = 0;
+    if (lane == leader) base = atomicAdd(counter, (uint32_t)__popcll(mask));
+    base = __shfl(base, leader);
+    if (pred) queue[base + __popcll(mask & ((1ull << lane) - 1ull))] = value;
+}
+__device__ __forceinline__ void wave_add64(unsigned long long v, unsigned long long* dst) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
+    if (__lane_id() == 0 && v) atomicAdd(dst, v);
+}
+
+// XCD-aware block remap: blocks b and b+8 share an XCD (and its L2); give each XCD a contiguous
+// range of path slots so neighbouring pixels' BVH nodes stay in one L2.
+__device__ __forceinline__ uint32_t xcd_block(uint32_t b, uint32_t nb) {
+    const uint32_t per = nb >> 3;
+    if (per == 0 || b >= per * 8) return b;
+    return (b & 7u) * per + (b >> 3);
+}
+
+// ---------------------------------------------------------------------- init
+__global__ void __launch_bounds__(kBlock) k_init(DPaths P, Params prm, uint32_t n, uint32_t pix_base, uint32_t npix_chunk,
+                                                 const uint32_t* cnt, uint32_t sample_offset, uint32_t sample_stride,
+                                                 const uint32_t* list_pix, const uint32_t* list_smp) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        uint32_t pixel, sample;
+        if (list_pix) { pixel = list_pix[i]; sample = list_smp[i]; }
+        else {
+            const uint32_t s = i / npix_chunk;
+            pixel = pix_base + (i - s * npix_chunk);
+            sample = sample_offset + (cnt[pixel] + s) * sample_stride;
+        }
+        P.pix[i] = pixel; P.smp[i] = sample; P.draw[i] = 2;     // draws 0,1 = lens (utils.cpp:70,73)
+        const F3 one = f3(1.0f, 1.0f, 1.0f), zero = f3(0.0f, 0.0f, 0.0f);
+        PT_ST3(P.T, P.cap, i, one); PT_ST3(P.C, P.cap, i, zero);
+    }
+}
+
+// ---------------------------------------------------------------------- extend (closest hit)
+template <bool COUNT>
+__global__ void __launch_bounds__(kBlock) k_extend(DScene S, DCamera cam, DPaths P, Params prm, uint32_t bounce, uint32_t n0) {
+    const uint32_t n = bounce == 0 ? n0 : P.counts[bounce];
+    const uint32_t* q = bounce == 0 ? nullptr : P.queue[bounce & 1];
+    WorkCounters wc; wc.nodes = 0; wc.tris = 0;
+    const uint32_t nb = gridDim.x;
+    for (uint32_t base = xcd_block(blockIdx.x, nb) * kBlock; base < n; base += nb * kBlock) {
+        const uint32_t i = base + threadIdx.x;
+        if (i >= n) continue;
+        const uint32_t slot = q ? q[i] : i;
+        Ray r;
+        if (bounce == 0) { F3 rd, td; camera_rays(cam, prm.seed, P.pix[slot], P.smp[slot], prm.width, true, r, rd, td); }
+        else { r.p = f3(P.ray[slot], P.ray[(size_t)P.cap + slot], P.ray[2 * (size_t)P.cap + slot]);
+               r.d = f3(P.ray[3 * (size_t)P.cap + slot], P.ray[4 * (size_t)P.cap + slot], P.ray[5 * (size_t)P.cap + slot]); }
+        const HitRec h = trace_closest<COUNT>(S, r, wc);
+        P.ht[slot] = h.t; P.hinst[slot] = h.inst; P.hmesh[slot] = h.mesh; P.hslot[slot] = h.slot;
+    }
+    if (COUNT) { wave_add64(wc.nodes, &P.stat[3]); wave_add64(wc.tris, &P.stat[4]); }
+}
+
+// ---------------------------------------------------------------------- shade
+// RenderPixel's loop body for one bounce (render.h:121-206) minus the two visibility traces,
+// which are queued for k_connect.
+__global__ void __launch_bounds__(kBlock) k_shade(DScene S, DCamera cam, DPaths P, Params prm, uint32_t bounce, uint32_t n0) {
+    const uint32_t n = bounce == 0 ? n0 : P.counts[bounce];
+    const uint32_t* q = bounce == 0 ? nullptr : P.queue[bounce & 1];
+    uint32_t* qnext = P.queue[(bounce + 1) & 1];
+    const uint32_t nround = (n + 63u) & ~63u;
+    const size_t cap = P.cap;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < nround; i += gridDim.x * blockDim.x) {
+        bool alive = false, shadow = false;
+        uint32_t slot = 0;
+        if (i < n) {
+            slot = q ? q[i] : i;
+            const uint32_t pixel = P.pix[slot], sample = P.smp[slot];
+            Rng rng; rng.init(prm.seed, pixel, sample, P.draw[slot]);
+            Ray r; F3 rd = f3(0, 0, 0), td = f3(0, 0, 0);
+            const bool hasDiff = bounce == 0;
+            if (bounce == 0) camera_rays(cam, prm.seed, pixel, sample, prm.width, true, r, rd, td);
+            else { r.p = f3(P.ray[slot], P.ray[cap + slot], P.ray[2 * cap + slot]);
+                   r.d = f3(P.ray[3 * cap + slot], P.ray[4 * cap + slot], P.ray[5 * cap + slot]); }
+            HitRec hr; hr.t = P.ht[slot]; hr.inst = P.hinst[slot]; hr.mesh = P.hmesh[slot]; hr.slot = P.hslot[slot];
+            F3 T = PT_LD3(P.T, cap, slot), C = PT_LD3(P.C, cap, slot);
+            if (hr.inst < 0) {                                     // render.h:124-128
+                C = C + T * sample_environment(S, r.d);
+                PT_ST3(P.C, cap, slot, C);
+            } else {
+                Surf h;
+                surf_from_hit(S, hr, r, hasDiff, rd, td, h);
+                const int hitLight = S.nodes[h.node].light;
+                if (hitLight >= 0 && bounce == 0) C = C + T * ld3(S.lights[hitLight].intensity);   // :137-141
+                F3 wo = -1.0f * r.d;
+                wo = wo / len(wo);
+                MatCtx m;
+                mat_prepare(S, h, m);
+                // ---- SampleLights / EstimateDirect (render.h:26-105)
+                uint32_t flags = 0;
+                if (S.num_lights > 0) {
+                    const float selectPdf = 1.0f / S.num_lights;
+                    const int li = rng.next() % S.num_lights;
+                    if (li != hitLight) {
+                        const DLight& L = S.lights[li];
+                        const F3 Le = ld3(L.intensity);
+                        F3 sp, sn;
+                        light_sample_point(S, L, rng, sp, sn);
+                        const F3 wi1 = normalized(sp - h.p);
+                        const float dist = len(h.p - sp);
+                        const float pdf1 = light_pdf(L, h.p, sp, sn, dist);
+                        F3 c1 = f3(0, 0, 0);
+                        if (pdf1 > 0.0f && max3(Le) > 0.0f) {
+                            const F3 f = mat_eval(m, wi1, wo);
+                            const float NdotL = cymax(dot(m.brdfN, wi1), 0.0f);
+                            const float bp = mat_pdf(m, wi1, wo);
+                            if (bp > 0.0f) {
+                                const float w = (pdf1 * pdf1) / (pdf1 * pdf1 + bp * bp);
+                                c1 = NdotL * f * Le * w / pdf1;
+                                if (!(c1.x == 0.0f && c1.y == 0.0f && c1.z == 0.0f)) flags |= 1u;
+                            }
+                        }
+                        F3 wi2; float pdf2;
+                        mat_sample(m, wo, rng, wi2, pdf2);
+                        const F3 f2 = mat_eval(m, wi2, wo);
+                        F3 A2 = f3(0, 0, 0);
+                        if (pdf2 > 0.0f && sum3(f2) > 0.0f) {
+                            const float NdotL2 = cymax(dot(m.brdfN, wi2), 0.0f);
+                            A2 = NdotL2 * f2 * Le;
+                            flags |= 2u;
+                        }
+                        if (flags) {
+                            const F3 so = h.p + h.N * kBias;
+                            float* sh = P.sh + slot;
+#define PT_SH(f) sh[(size_t)(f) * cap]
+                            PT_SH(SH_OX) = so.x; PT_SH(SH_OY) = so.y; PT_SH(SH_OZ) = so.z;
+                            PT_SH(SH_W1X) = wi1.x; PT_SH(SH_W1Y) = wi1.y; PT_SH(SH_W1Z) = wi1.z; PT_SH(SH_TMAX1) = dist;
+                            PT_SH(SH_C1X) = c1.x; PT_SH(SH_C1Y) = c1.y; PT_SH(SH_C1Z) = c1.z;
+                            PT_SH(SH_W2X) = wi2.x; PT_SH(SH_W2Y) = wi2.y; PT_SH(SH_W2Z) = wi2.z;
+                            PT_SH(SH_A2X) = A2.x; PT_SH(SH_A2Y) = A2.y; PT_SH(SH_A2Z) = A2.z; PT_SH(SH_PDFB) = pdf2;
+                            PT_SH(SH_HPX) = h.p.x; PT_SH(SH_HPY) = h.p.y; PT_SH(SH_HPZ) = h.p.z;
+                            PT_SH(SH_TBX) = T.x; PT_SH(SH_TBY) = T.y; PT_SH(SH_TBZ) = T.z; PT_SH(SH_SELPDF) = selectPdf;
+                            PT_SH(SH_FLAGS) = __uint_as_float(flags); PT_SH(SH_LIGHT) = __int_as_float(li);
+#undef PT_SH
+                            shadow = true;
+                        }
+                    }
+                    if (!flags) C = C + T * (f3(0, 0, 0) / selectPdf);   // throughput * black keeps NaN/Inf semantics
+                }
+                // ---- continuation (render.h:150-205)
+                F3 wi; float pdf;
+                mat_sample(m, wo, rng, wi, pdf);
+                const F3 f = mat_eval(m, wi, wo);
+                const float NdotL = cymax(dot(m.brdfN, wi), 0.0f);
+                T = T * NdotL * f / pdf;
+                const F3 np = h.p + wi * kBias;
+                alive = true;
+                if (bounce > prm.rr_start) {
+                    const float p = cymax(max3(T), 0.001f);
+                    const float random = rng.U();
+                    if (random > p) alive = false;
+                    else T = T * (1.0f / p);
+                }
+                if (bounce + 1 >= prm.max_bounces) alive = false;
+                PT_ST3(P.C, cap, slot, C);
+                if (alive) {
+                    PT_ST3(P.T, cap, slot, T);
+                    P.ray[slot] = np.x; P.ray[cap + slot] = np.y; P.ray[2 * cap + slot] = np.z;
+                    P.ray[3 * cap + slot] = wi.x; P.ray[4 * cap + slot] = wi.y; P.ray[5 * cap + slot] = wi.z;
+                    P.draw[slot] = rng.draw;
+                }
+            }
+        }
+        wave_enqueue(alive, slot, qnext, &P.counts[bounce + 1]);
+        wave_enqueue(shadow, slot, P.squeue, &P.scounts[bounce]);
+    }
+}
+
+// ---------------------------------------------------------------------- connect (NEE shadow ray + MIS)
+// LightComponent::SampleLi visibility, LightComponent::Pdf(wi), PowerHeuristic and the
+// `color += throughput * SampleLights(...)` of render.h:148.
+template <bool COUNT>
+__global__ void __launch_bounds__(kBlock) k_connect(DScene S, DPaths P, uint32_t bounce) {
+    const uint32_t n = P.scounts[bounce];
+    const size_t cap = P.cap;
+    WorkCounters wc; wc.nodes = 0; wc.tris = 0;
+    unsigned long long rays = 0;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const uint32_t slot = P.squeue[i];
+        const float* sh = P.sh + slot;
+#define PT_SH(f) sh[(size_t)(f) * cap]
+        const uint32_t flags = __float_as_uint(PT_SH(SH_FLAGS));
+        const DLight& L = S.lights[__float_as_int(PT_SH(SH_LIGHT))];
+        Ray r; r.p = f3(PT_SH(SH_OX), PT_SH(SH_OY), PT_SH(SH_OZ));
+        F3 direct = f3(0, 0, 0);
+        F3 lp, ln;
+        if (flags & 1u) {
+            r.d = f3(PT_SH(SH_W1X), PT_SH(SH_W1Y), PT_SH(SH_W1Z));
+            rays++;
+            if (!light_vis_test<COUNT>(S, r, PT_SH(SH_TMAX1), L, lp, ln, wc))
+                direct = direct + f3(PT_SH(SH_C1X), PT_SH(SH_C1Y), PT_SH(SH_C1Z));
+        }
+        if (flags & 2u) {
+            r.d = f3(PT_SH(SH_W2X), PT_SH(SH_W2Y), PT_SH(SH_W2Z));
+            rays++;
+            if (!light_vis_test<COUNT>(S, r, kBig, L, lp, ln, wc)) {
+                const F3 hp = f3(PT_SH(SH_HPX), PT_SH(SH_HPY), PT_SH(SH_HPZ));
+                const float lightPdf = light_pdf(L, hp, lp, ln, len(lp - hp));
+                if (!(lightPdf <= 0.0f)) {
+                    const float pb = PT_SH(SH_PDFB);
+                    const float w = (pb * pb) / (pb * pb + lightPdf * lightPdf);
+                    direct = direct + f3(PT_SH(SH_A2X), PT_SH(SH_A2Y), PT_SH(SH_A2Z)) * w / pb;
+                }
+            }
+        }
+        const F3 Tb = f3(PT_SH(SH_TBX), PT_SH(SH_TBY), PT_SH(SH_TBZ));
+        F3 C = PT_LD3(P.C, cap, slot);
+        C = C + Tb * (direct / PT_SH(SH_SELPDF));
+        PT_ST3(P.C, cap, slot, C);
+#undef PT_SH
+    }
+    wave_add64(rays, &P.stat[1]);
+    if (COUNT) { wave_add64(wc.nodes, &P.stat[3]); wave_add64(wc.tris, &P.stat[4]); }
+}
+
+// ---------------------------------------------------------------------- resolve
+// NaN/Inf -> black, ACES, gamma (render.h:218-243), running mean and RGB8 truncation
+// (pathtracer.cpp:76-101) for the `ns` samples of each pixel of the chunk, in sample order.
+__device__ __forceinline__ F3 finish_sample(F3 c, F3* linear) {
+    const float s = sum3(c);
+    if (isnan(s) || isinf(s)) c = f3(0, 0, 0);
+    if (linear) *linear = c;
+    const F3 m = aces(c);
+    return f3(powf(m.x, 0.4545f), powf(m.y, 0.4545f), powf(m.z, 0.4545f));
+}
+__global__ void __launch_bounds__(kBlock) k_resolve(DPaths P, float* mean, uint32_t* cnt, uint8_t* rgb8, uint32_t pix_base,
+                                                    uint32_t npix_chunk, uint32_t ns) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < npix_chunk; i += gridDim.x * blockDim.x) {
+        const uint32_t pixel = pix_base + i;
+        F3 c = f3(mean[3 * (size_t)pixel], mean[3 * (size_t)pixel + 1], mean[3 * (size_t)pixel + 2]);
+        uint32_t n = cnt[pixel];
+        for (uint32_t s = 0; s < ns; s++) {
+            const uint32_t slot = s * npix_chunk + i;
+            const F3 smp = finish_sample(PT_LD3(P.C, P.cap, slot), nullptr);
+            n += 1;
+            const float factor = 1.0f / (float)n;
+            c = ((float)(n - 1) * c + smp) * factor;
+        }
+        mean[3 * (size_t)pixel] = c.x; mean[3 * (size_t)pixel + 1] = c.y; mean[3 * (size_t)pixel + 2] = c.z;
+        cnt[pixel] = n;
+        rgb8[3 * (size_t)pixel] = (uint8_t)(c.x * 255.0f); rgb8[3 * (size_t)pixel + 1] = (uint8_t)(c.y * 255.0f);
+        rgb8[3 * (size_t)pixel + 2] = (uint8_t)(c.z * 255.0f);
+    }
+}
+__global__ void __launch_bounds__(kBlock) k_gather(DPaths P, uint32_t n, float* linear, float* mapped) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        F3 lin;
+        const F3 m = finish_sample(PT_LD3(P.C, P.cap, i), &lin);
+        if (linear) { linear[3 * (size_t)i] = lin.x; linear[3 * (size_t)i + 1] = lin.y; linear[3 * (size_t)i + 2] = lin.z; }
+        if (mapped) { mapped[3 * (size_t)i] = m.x; mapped[3 * (size_t)i + 1] = m.y; mapped[3 * (size_t)i + 2] = m.z; }
+    }
+}
+__global__ void k_stats(DPaths P, uint32_t n0, uint32_t max_bounces) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        unsigned long long c = n0;
+        for (uint32_t b = 1; b < max_bounces; b++) c += P.counts[b];
+        P.stat[0] += c; P.stat[2] += n0;
+    }
+}
+
+// ---------------------------------------------------------------------- primary-hit parity hook
+template <bool COUNT>
+__global__ void __launch_bounds__(kBlock) k_primary(DScene S, DCamera cam, Params prm, uint32_t x0, uint32_t y0, uint32_t rw, uint32_t rh,
+                                                    int32_t* node, int32_t* mesh, int32_t* face, float* t, unsigned long long* stat) {
+    WorkCounters wc; wc.nodes = 0; wc.tris = 0;
+    const uint32_t n = rw * rh;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const uint32_t ly = i / rw, lx = i - ly * rw;
+        const uint32_t pixel = (y0 + ly) * prm.width + (x0 + lx);
+        Ray r; F3 rd, td;
+        camera_rays(cam, prm.seed, pixel, 0, prm.width, false, r, rd, td);
+        const HitRec h = trace_closest<COUNT>(S, r, wc);
+        t[i] = h.t;
+        if (h.inst < 0) { node[i] = -1; mesh[i] = -1; face[i] = -1; }
+        else {
+            const DInst& in = S.insts[h.inst];
+            node[i] = in.node; mesh[i] = h.mesh; face[i] = -1;
+            if (in.kind == MI355PT_OBJ_MODEL) {
+                const DMesh& M = S.meshes[S.models[in.model].first_mesh + h.mesh];
+                const Tri T = load_tri(S.tris, h.slot);
+                face[i] = (int32_t)S.faces[4 * (size_t)(M.face_base + T.face) + 3];
+            }
+        }
+    }
+    if (COUNT) { wave_add64(wc.nodes, &stat[3]); wave_add64(wc.tris, &stat[4]); }
+}
+
+// ====================================================================== host side
+namespace {
+
+thread_local std::string g_err;
+int fail(int code, const std::string& msg) { g_err = msg; return code; }
+#define HIP_TRY(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return fail(MI355PT_ERR_HIP, std::string(#x) + ": " + hipGetErrorString(e_)); } while (0)
+
+template <typename T>
+struct DevBuf {
+    T* p = nullptr; size_t n = 0;
+    hipError_t alloc(size_t count) { n = count; return hipMalloc((void**)&p, std::max<size_t>(count, 1) * sizeof(T)); }
+    hipError_t upload(const std::vector<T>& v) {
+        hipError_t e = alloc(v.size()); if (e != hipSuccess) return e;
+        if (!v.empty()) e = hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice);
+        return e;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
+};
+
+// host fp32 helpers (same expression trees as the device / reference)
+struct H3 { float x, y, z; };
+H3 h_m4mulp(const float* c, H3 p, float w) {
+    return H3{(p.x * c[0] + p.z * c[8]) + (p.y * c[4] + w * c[12]), (p.x * c[1] + p.z * c[9]) + (p.y * c[5] + w * c[13]),
+              (p.x * c[2] + p.z * c[10]) + (p.y * c[6] + w * c[14])};
+}
+float h_len(H3 a) { return sqrtf(a.x * a.x + a.y * a.y + a.z * a.z); }
+
+}  // namespace
+
+struct mi355pt_scene {
+    int device = 0;
+    DScene d{};
+    mi355pt_camera camera{};
+    std::vector<ptb::MeshTree> trees;
+    DevBuf<DNodeXf> nodes; DevBuf<DInst> insts; DevBuf<DModel> models; DevBuf<DMesh> meshes;
+    DevBuf<float4> bvh_nodes, tris; DevBuf<uint32_t> faces; DevBuf<float> normals, uvw, tangents, bitangents;
+    DevBuf<mi355pt_material> materials; DevBuf<mi355pt_texmap> texmaps; DevBuf<DTexture> textures; DevBuf<DLight> lights;
+    std::vector<void*> tex_data;
+    uint64_t num_tris = 0, num_bvh_nodes = 0; int max_depth = 0;
+    ~mi355pt_scene() {
+        nodes.release(); insts.release(); models.release(); meshes.release(); bvh_nodes.release(); tris.release(); faces.release();
+        normals.release(); uvw.release(); tangents.release(); bitangents.release(); materials.release(); texmaps.release();
+        textures.release(); lights.release();
+        for (void* p : tex_data) (void)hipFree(p);
+    }
+};
+
+struct mi355pt_render {
+    mi355pt_scene* scene = nullptr;
+    mi355pt_render_params prm{};
+    DCamera cam{};
+    DPaths P{};
+    hipStream_t stream = nullptr;
+    std::vector<void*> allocs;
+    float* mean = nullptr; uint32_t* cnt = nullptr; uint8_t* rgb8 = nullptr;
+    bool profiling = false, count_work = false;
+    struct Ev { hipEvent_t a, b; int kind; };
+    std::vector<Ev> events;
+    double ms[4] = {0, 0, 0, 0}; uint64_t extend_launches = 0;
+    int grid = 2048;
+    ~mi355pt_render() {
+        for (auto& e : events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+        for (void* p : allocs) (void)hipFree(p);
+        if (stream) (void)hipStreamDestroy(stream);
+    }
+};
+
+namespace {
+
+int check_device(int device) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return fail(MI355PT_ERR_NO_DEVICE, "no HIP device visible (there is no CPU fallback)");
+    if (device < 0 || device >= n) return fail(MI355PT_ERR_NO_DEVICE, "device ordinal out of range");
+    hipDeviceProp_t p;
+    if (hipGetDeviceProperties(&p, device) != hipSuccess) return fail(MI355PT_ERR_HIP, "hipGetDeviceProperties failed");
+    if (std::string(p.gcnArchName).find("gfx950") == std::string::npos)
+        return fail(MI355PT_ERR_NO_DEVICE, std::string("device is ") + p.gcnArchName + ", this library is built for gfx950 only");
+    return MI355PT_OK;
+}
+
+DCamera init_camera(const mi355pt_camera& c, uint32_t w, uint32_t h) {      // InitCamera, raytracer.cpp:318-333
+    DCamera d{};
+    float dx = c.dir[0], dy = c.dir[1], dz = c.dir[2];
+    const float l = sqrtf(dx * dx + dy * dy + dz * dz);
+    dx /= l; dy /= l; dz /= l;
+    for (int i = 0; i < 3; i++) { d.pos[i] = c.pos[i]; d.up[i] = c.up[i]; }
+    d.front[0] = dx; d.front[1] = dy; d.front[2] = dz;
+    d.right[0] = dy * c.up[2] - dz * c.up[1]; d.right[1] = dz * c.up[0] - dx * c.up[2]; d.right[2] = dx * c.up[1] - dy * c.up[0];
+    d.plane_h = c.focaldist * tanf(c.fov * 0.5f / 180.0f * static_cast<float>(M_PI)) * 2.0f;
+    d.plane_w = d.plane_h * static_cast<float>((int)w) / static_cast<float>((int)h);
+    d.texel_w = d.plane_w / static_cast<float>((int)w);
+    d.texel_h = d.plane_h / static_cast<float>((int)h);
+    d.focaldist = c.focaldist; d.dof = c.dof;
+    return d;
+}
+
+}  // namespace
+
+// ====================================================================== C ABI
+extern "C" {
+
+const char* mi355pt_version(void) { return "mi355pt 0.1 (gfx950)"; }
+const char* mi355pt_last_error(void) { return g_err.c_str(); }
+
+int mi355pt_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    int ok = 0;
+    for (int i = 0; i < n; i++) {
+        hipDeviceProp_t p;
+        if (hipGetDeviceProperties(&p, i) == hipSuccess && std::string(p.gcnArchName).find("gfx950") != std::string::npos) ok++;
+    }
+    return ok;
+}
+
+int mi355pt_scene_create(const mi355pt_scene_desc* desc, int32_t device, mi355pt_scene** out) {
+    if (!desc || !out || !desc->nodes || desc->num_nodes == 0) return fail(MI355PT_ERR_INVALID, "null scene description");
+    if (int rc = check_device(device)) return rc;
+    HIP_TRY(hipSetDevice(device));
+    std::unique_ptr<mi355pt_scene> sc(new mi355pt_scene());
+    sc->device = device; sc->camera = desc->camera;
+
+    // ---- nodes, instances (object-bearing nodes in depth-first pre-order = array order)
+    std::vector<DNodeXf> nodes(desc->num_nodes);
+    std::vector<DInst> insts;
+    std::vector<int> inst_of_node(desc->num_nodes, -1);
+    for (uint32_t i = 0; i < desc->num_nodes; i++) {
+        const mi355pt_node& s = desc->nodes[i];
+        if (i == 0 ? s.parent != -1 : (s.parent < 0 || (uint32_t)s.parent >= i)) return fail(MI355PT_ERR_INVALID, "nodes must be in depth-first pre-order");
+        DNodeXf& d = nodes[i];
+        memcpy(d.tm, s.tm, sizeof(d.tm)); memcpy(d.itm, s.itm, sizeof(d.itm)); memcpy(d.pos, s.pos, sizeof(d.pos));
+        memcpy(d.l2w, s.local_to_world, sizeof(d.l2w));
+        d.material = s.material; d.light = s.light; d.pad0 = d.pad1 = 0;
+        if (s.object_kind == MI355PT_OBJ_NONE) continue;
+        if (s.object_kind != MI355PT_OBJ_PLANE && s.object_kind != MI355PT_OBJ_MODEL) return fail(MI355PT_ERR_UNSUPPORTED, "object kind not supported (Sphere is a later row)");
+        if (s.material < 0 || (uint32_t)s.material >= desc->num_materials) return fail(MI355PT_ERR_INVALID, "object node without material");
+        if (s.object_kind == MI355PT_OBJ_MODEL && (s.object_index < 0 || (uint32_t)s.object_index >= desc->num_models)) return fail(MI355PT_ERR_INVALID, "bad model index");
+        DInst in{}; in.node = (int)i; in.kind = s.object_kind; in.model = s.object_index;
+        std::vector<int> chain;
+        for (int c = (int)i; c >= 0; c = desc->nodes[c].parent) chain.push_back(c);
+        if (chain.size() > MI355PT_MAX_CHAIN) return fail(MI355PT_ERR_TOO_LARGE, "scene graph deeper than MI355PT_MAX_CHAIN");
+        in.chain_len = (int)chain.size();
+        for (int k = 0; k < in.chain_len; k++) in.chain[k] = chain[chain.size() - 1 - k];
+        inst_of_node[i] = (int)insts.size();
+        insts.push_back(in);
+    }
+    // ---- lights
+    std::vector<DLight> lights(desc->num_lights);
+    for (uint32_t i = 0; i < desc->num_lights; i++) {
+        const mi355pt_light& s = desc->lights[i];
+        if (s.node < 0 || (uint32_t)s.node >= desc->num_nodes || desc->nodes[s.node].object_kind != MI355PT_OBJ_PLANE)
+            return fail(MI355PT_ERR_UNSUPPORTED, "lights must sit on Plane nodes (mesh lights are a later row)");
+        DLight& d = lights[i];
+        d.node = s.node; memcpy(d.intensity, s.intensity, sizeof(d.intensity)); d.inst = inst_of_node[s.node]; d.pad0 = d.pad1 = 0;
+        const float* m = desc->nodes[s.node].local_to_world;       // Plane::Area, objects.cpp:496-503
+        const H3 zero = h_m4mulp(m, H3{0, 0, 0}, 1.0f), wv = h_m4mulp(m, H3{2, 0, 0}, 1.0f), hv = h_m4mulp(m, H3{0, 2, 0}, 1.0f);
+        d.area = h_len(H3{wv.x - zero.x, wv.y - zero.y, wv.z - zero.z}) * h_len(H3{hv.x - zero.x, hv.y - zero.y, hv.z - zero.z});
+    }
+    // ---- meshes: BVH build / import, flatten, pack
+    std::vector<DModel> models(desc->num_models);
+    for (uint32_t i = 0; i < desc->num_models; i++) {
+        const mi355pt_model& s = desc->models[i];
+        if (s.first_mesh < 0 || s.num_meshes < 0 || (uint32_t)(s.first_mesh + s.num_meshes) > desc->num_meshes) return fail(MI355PT_ERR_INVALID, "bad model mesh range");
+        memcpy(models[i].aabb, s.aabb, sizeof(s.aabb)); models[i].first_mesh = s.first_mesh; models[i].num_meshes = s.num_meshes;
+    }
+    std::vector<DMesh> meshes(desc->num_meshes);
+    std::vector<float4> bvh_nodes, tris;
+    std::vector<uint32_t> faces; std::vector<float> normals, uvw, tangents, bitangents;
+    sc->trees.resize(desc->num_meshes);
+    const int threads = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+    for (uint32_t mi = 0; mi < desc->num_meshes; mi++) {
+        const mi355pt_mesh& s = desc->meshes[mi];
+        if (!s.vertices || !s.faces || !s.normals || !s.uvw) return fail(MI355PT_ERR_INVALID, "mesh needs vertices, normals, uvw and faces");
+        for (size_t k = 0; k < (size_t)s.num_faces; k++)
+            for (int c = 0; c < 3; c++) if (s.faces[4 * k + c] >= s.num_vertices) return fail(MI355PT_ERR_INVALID, "face index out of range");
+        ptb::MeshTree& tree = sc->trees[mi];
+        if (s.bvh_nodes && s.num_bvh_nodes) {
+            if (!ptb::import_tree(s.bvh_nodes, s.num_bvh_nodes, s.bvh_faces, s.num_bvh_faces, s.num_faces, tree)) return fail(MI355PT_ERR_INVALID, "malformed BVH in mesh");
+        } else {
+            ptb::build_tree(s.vertices, s.faces, s.num_faces, s.aabb, threads, tree);
+        }
+        if (tree.max_depth + 2 > kStackSize) return fail(MI355PT_ERR_TOO_LARGE, "BVH deeper than the traversal stack");
+        sc->max_depth = std::max(sc->max_depth, tree.max_depth);
+        ptb::FlatMesh flat;
+        ptb::flatten_tree(tree, flat);
+        DMesh& d = meshes[mi];
+        memcpy(d.aabb, s.aabb, sizeof(d.aabb)); memcpy(d.root_bound, tree.nodes[0].bound, sizeof(d.root_bound));
+        const uint32_t node_base = (uint32_t)(bvh_nodes.size() / 4), tri_base = (uint32_t)(tris.size() / 3);
+        if ((uint64_t)tri_base + flat.slot_face.size() > 0xFFFFFFF0ull) return fail(MI355PT_ERR_TOO_LARGE, "more than 2^32 triangles");
+        d.face_base = (uint32_t)(faces.size() / 4); d.vert_base = (uint32_t)(normals.size() / 3);
+        d.has_tangents = (s.tangents && s.bitangents) ? 1 : 0; d.pad = 0;
+        const bool root_internal = flat.root_cnt == ptb::kInternal;
+        d.root_ref = root_internal ? node_base : tri_base + flat.root_ref; d.root_cnt = flat.root_cnt;
+        // node records: rebase references to the global pools
+        const size_t nrec = flat.node_words.size() / 16;
+        bvh_nodes.resize(bvh_nodes.size() + 4 * nrec);
+        for (size_t r = 0; r < nrec; r++) {
+            float w[16]; memcpy(w, &flat.node_words[16 * r], sizeof(w));
+            uint32_t u[4]; memcpy(u, &w[12], sizeof(u));
+            for (int c = 0; c < 2; c++) u[c] += (u[2 + c] == ptb::kInternal) ? node_base : tri_base;
+            memcpy(&w[12], u, sizeof(u));
+            memcpy(&bvh_nodes[4 * ((size_t)node_base + r)], w, sizeof(w));
+        }
+        // triangle slots: v0 v1 v2 + position of the face in faces[]
+        tris.resize(tris.size() + 3 * flat.slot_face.size());
+        for (size_t k = 0; k < flat.slot_face.size(); k++) {
+            const uint32_t fpos = flat.slot_face[k];
+            const uint32_t* f = s.faces + 4 * (size_t)fpos;
+            const float* a = s.vertices + 3 * (size_t)f[0]; const float* b = s.vertices + 3 * (size_t)f[1]; const float* c = s.vertices + 3 * (size_t)f[2];
+            float4* t = &tris[3 * ((size_t)tri_base + k)];
+            t[0] = make_float4(a[0], a[1], a[2], b[0]); t[1] = make_float4(b[1], b[2], c[0], c[1]);
+            float fid; memcpy(&fid, &fpos, 4);
+            t[2] = make_float4(c[2], fid, 0.0f, 0.0f);
+        }
+        faces.insert(faces.end(), s.faces, s.faces + 4 * (size_t)s.num_faces);
+        normals.insert(normals.end(), s.normals, s.normals + 3 * (size_t)s.num_vertices);
+        uvw.insert(uvw.end(), s.uvw, s.uvw + 3 * (size_t)s.num_vertices);
+        if (d.has_tangents) {
+            tangents.resize(3 * (size_t)d.face_base, 0.0f); bitangents.resize(3 * (size_t)d.face_base, 0.0f);
+            tangents.insert(tangents.end(), s.tangents, s.tangents + 3 * (size_t)s.num_faces);
+            bitangents.insert(bitangents.end(), s.bitangents, s.bitangents + 3 * (size_t)s.num_faces);
+        }
+    }
+    sc->num_tris = tris.size() / 3; sc->num_bvh_nodes = bvh_nodes.size() / 4;
+    // ---- materials / textures
+    std::vector<mi355pt_material> materials(desc->materials, desc->materials + desc->num_materials);
+    std::vector<mi355pt_texmap> texmaps(desc->texmaps, desc->texmaps + desc->num_texmaps);
+    auto bad_map = [&](int m) { return m >= (int)desc->num_texmaps; };
+    for (auto& m : materials) if (bad_map(m.albedo_map) || bad_map(m.roughness_map) || bad_map(m.metalness_map) || bad_map(m.normal_map)) return fail(MI355PT_ERR_INVALID, "bad texmap index");
+    for (auto& m : texmaps) if (m.texture >= (int)desc->num_textures) return fail(MI355PT_ERR_INVALID, "bad texture index");
+    if (bad_map(desc->env_map)) return fail(MI355PT_ERR_INVALID, "bad environment map index");
+    std::vector<DTexture> textures(desc->num_textures);
+    for (uint32_t i = 0; i < desc->num_textures; i++) {
+        const mi355pt_texture& s = desc->textures[i]; DTexture& d = textures[i];
+        d.kind = s.kind; d.width = s.width; d.height = s.height; d.pad = 0; d.data = nullptr;
+        memcpy(d.c1, s.color1, sizeof(d.c1)); memcpy(d.c2, s.color2, sizeof(d.c2));
+        const size_t n = (size_t)s.width * s.height;
+        if (s.kind == MI355PT_TEX_RGB8 && s.data && n) {           // padded to RGBA8 for aligned 4-byte texel loads
+            std::vector<uchar4> px(n); const uint8_t* b = (const uint8_t*)s.data;
+            for (size_t k = 0; k < n; k++) px[k] = make_uchar4(b[3 * k], b[3 * k + 1], b[3 * k + 2], 255);
+            void* p; HIP_TRY(hipMalloc(&p, n * sizeof(uchar4))); sc->tex_data.push_back(p);
+            HIP_TRY(hipMemcpy(p, px.data(), n * sizeof(uchar4), hipMemcpyHostToDevice)); d.data = p;
+        } else if (s.kind == MI355PT_TEX_RGB32F && s.data && n) {
+            std::vector<float4> px(n); const float* b = (const float*)s.data;
+            for (size_t k = 0; k < n; k++) px[k] = make_float4(b[3 * k], b[3 * k + 1], b[3 * k + 2], 1.0f);
+            void* p; HIP_TRY(hipMalloc(&p, n * sizeof(float4))); sc->tex_data.push_back(p);
+            HIP_TRY(hipMemcpy(p, px.data(), n * sizeof(float4), hipMemcpyHostToDevice)); d.data = p;
+        } else if (s.kind != MI355PT_TEX_CHECKER) { d.width = d.height = 0; }
+    }
+    // ---- upload
+    HIP_TRY(sc->nodes.upload(nodes)); HIP_TRY(sc->insts.upload(insts)); HIP_TRY(sc->models.upload(models)); HIP_TRY(sc->meshes.upload(meshes));
+    HIP_TRY(sc->bvh_nodes.upload(bvh_nodes)); HIP_TRY(sc->tris.upload(tris)); HIP_TRY(sc->faces.upload(faces));
+    HIP_TRY(sc->normals.upload(normals)); HIP_TRY(sc->uvw.upload(uvw)); HIP_TRY(sc->tangents.upload(tangents)); HIP_TRY(sc->bitangents.upload(bitangents));
+    HIP_TRY(sc->materials.upload(materials)); HIP_TRY(sc->texmaps.upload(texmaps)); HIP_TRY(sc->textures.upload(textures)); HIP_TRY(sc->lights.upload(lights));
+    DScene& d = sc->d;
+    d.nodes = sc->nodes.p; d.num_nodes = (int)nodes.size(); d.insts = sc->insts.p; d.num_insts = (int)insts.size();
+    d.models = sc->models.p; d.meshes = sc->meshes.p; d.bvh_nodes = sc->bvh_nodes.p; d.tris = sc->tris.p; d.faces = sc->faces.p;
+    d.normals = sc->normals.p; d.uvw = sc->uvw.p; d.tangents = sc->tangents.p; d.bitangents = sc->bitangents.p;
+    d.materials = sc->materials.p; d.texmaps = sc->texmaps.p; d.textures = sc->textures.p; d.lights = sc->lights.p; d.num_lights = (int)lights.size();
+    memcpy(d.env_color, desc->env_color, sizeof(d.env_color)); d.env_map = desc->env_map;
+    *out = sc.release();
+    return MI355PT_OK;
+}
+
+void mi355pt_scene_destroy(mi355pt_scene* scene) { if (scene) { (void)hipSetDevice(scene->device); delete scene; } }
+
+int mi355pt_scene_get_bvh(const mi355pt_scene* scene, uint32_t mesh, mi355pt_bvh_node* nodes, uint32_t* num_nodes, uint32_t* faces, uint32_t* num_faces) {
+    if (!scene || mesh >= scene->trees.size() || !num_nodes || !num_faces) return fail(MI355PT_ERR_INVALID, "bad argument");
+    std::vector<mi355pt_bvh_node> n; std::vector<uint32_t> f;
+    ptb::export_tree(scene->trees[mesh], n, f);
+    if (nodes && faces) {
+        if (*num_nodes < n.size() || *num_faces < f.size()) return fail(MI355PT_ERR_INVALID, "buffers too small");
+        memcpy(nodes, n.data(), n.size() * sizeof(n[0])); memcpy(faces, f.data(), f.size() * sizeof(uint32_t));
+    }
+    *num_nodes = (uint32_t)n.size(); *num_faces = (uint32_t)f.size();
+    return MI355PT_OK;
+}
+
+int mi355pt_build_bvh(const float* vertices, uint32_t num_vertices, const uint32_t* faces, uint32_t num_faces, const float aabb[6],
+                      mi355pt_bvh_node* nodes, uint32_t* num_nodes, uint32_t* bvh_faces, uint32_t* num_bvh_faces) {
+    if (!vertices || !faces || !aabb || !num_nodes || !num_bvh_faces) return fail(MI355PT_ERR_INVALID, "null argument");
+    for (size_t k = 0; k < (size_t)num_faces; k++)
+        for (int c = 0; c < 3; c++) if (faces[4 * k + c] >= num_vertices) return fail(MI355PT_ERR_INVALID, "face index out of range");
+    ptb::MeshTree tree;
+    ptb::build_tree(vertices, faces, num_faces, aabb, (int)std::max(1u, std::min(16u, std::thread::hardware_concurrency())), tree);
+    std::vector<mi355pt_bvh_node> n; std::vector<uint32_t> f;
+    ptb::export_tree(tree, n, f);
+    if (nodes && bvh_faces) {
+        if (*num_nodes < n.size() || *num_bvh_faces < f.size()) return fail(MI355PT_ERR_INVALID, "buffers too small");
+        memcpy(nodes, n.data(), n.size() * sizeof(n[0])); memcpy(bvh_faces, f.data(), f.size() * sizeof(uint32_t));
+    }
+    *num_nodes = (uint32_t)n.size(); *num_bvh_faces = (uint32_t)f.size();
+    return MI355PT_OK;
+}
+
+int mi355pt_render_create(mi355pt_scene* scene, const mi355pt_render_params* params, mi355pt_render** out) {
+    if (!scene || !params || !out) return fail(MI355PT_ERR_INVALID, "null argument");
+    if (params->width == 0 || params->height == 0 || params->max_bounces == 0 || params->sample_stride == 0) return fail(MI355PT_ERR_INVALID, "bad render parameters");
+    if ((uint64_t)params->width * params->height > 0x7FFFFFFFull) return fail(MI355PT_ERR_TOO_LARGE, "image too large");
+    if (params->device != scene->device) return fail(MI355PT_ERR_INVALID, "renderer and scene must be on the same device");
+    HIP_TRY(hipSetDevice(scene->device));
+    std::unique_ptr<mi355pt_render> r(new mi355pt_render());
+    r->scene = scene; r->prm = *params;
+    r->cam = init_camera(scene->camera, params->width, params->height);
+    HIP_TRY(hipStreamCreateWithFlags(&r->stream, hipStreamNonBlocking));
+    const size_t npix = (size_t)params->width * params->height;
+    size_t cap = 8388608;
+    if (const char* e = getenv("MI355PT_MAX_PATHS")) cap = std::max<size_t>(65536, strtoull(e, nullptr, 10));
+    cap = std::min(cap, std::max<size_t>(npix, 65536) * 64);
+    cap = (cap + 63) & ~(size_t)63;
+    auto dalloc = [&](void** p, size_t bytes) -> hipError_t { hipError_t e = hipMalloc(p, bytes); if (e == hipSuccess) r->allocs.push_back(*p); return e; };
+    DPaths& P = r->P; P.cap = (uint32_t)cap;
+    HIP_TRY(dalloc((void**)&P.pix, cap * 4)); HIP_TRY(dalloc((void**)&P.smp, cap * 4)); HIP_TRY(dalloc((void**)&P.draw, cap * 4));
+    HIP_TRY(dalloc((void**)&P.ray, cap * 24)); HIP_TRY(dalloc((void**)&P.T, cap * 12)); HIP_TRY(dalloc((void**)&P.C, cap * 12));
+    HIP_TRY(dalloc((void**)&P.ht, cap * 4)); HIP_TRY(dalloc((void**)&P.hinst, cap * 4)); HIP_TRY(dalloc((void**)&P.hmesh, cap * 4)); HIP_TRY(dalloc((void**)&P.hslot, cap * 4));
+    HIP_TRY(dalloc((void**)&P.sh, cap * 4 * kShFields));
+    HIP_TRY(dalloc((void**)&P.queue[0], cap * 4)); HIP_TRY(dalloc((void**)&P.queue[1], cap * 4)); HIP_TRY(dalloc((void**)&P.squeue, cap * 4));
+    const size_t nb = params->max_bounces + 2;
+    HIP_TRY(dalloc((void**)&P.counts, nb * 4)); HIP_TRY(dalloc((void**)&P.scounts, nb * 4));
+    HIP_TRY(dalloc((void**)&P.stat, 8 * sizeof(unsigned long long)));
+    HIP_TRY(hipMemset(P.stat, 0, 8 * sizeof(unsigned long long)));
+    HIP_TRY(dalloc((void**)&r->mean, npix * 12)); HIP_TRY(dalloc((void**)&r->cnt, npix * 4)); HIP_TRY(dalloc((void**)&r->rgb8, npix * 3));
+    HIP_TRY(hipMemset(r->mean, 0, npix * 12)); HIP_TRY(hipMemset(r->cnt, 0, npix * 4)); HIP_TRY(hipMemset(r->rgb8, 0, npix * 3));
+    hipDeviceProp_t prop; HIP_TRY(hipGetDeviceProperties(&prop, scene->device));
+    r->grid = prop.multiProcessorCount * 8;
+    r->count_work = getenv("MI355PT_COUNT_WORK") != nullptr;
+    *out = r.release();
+    return MI355PT_OK;
+}
+
+void mi355pt_render_destroy(mi355pt_render* render) {
+    if (!render) return;
+    (void)hipSetDevice(render->scene->device);
+    (void)hipStreamSynchronize(render->stream);
+    delete render;
+}
+
+}  // extern "C"
+
+namespace {
+
+int grid_for(const mi355pt_render* r, size_t n) {
+    size_t b = (n + kBlock - 1) / kBlock;
+    return (int)std::max<size_t>(1, std::min<size_t>(b, (size_t)r->grid));
+}
+void ev_begin(mi355pt_render* r, int kind) {
+    if (!r->profiling) return;
+    mi355pt_render::Ev e; e.kind = kind;
+    (void)hipEventCreate(&e.a); (void)hipEventCreate(&e.b);
+    (void)hipEventRecord(e.a, r->stream);
+    r->events.push_back(e);
+}
+void ev_end(mi355pt_render* r) {
+    if (!r->profiling) return;
+    (void)hipEventRecord(r->events.back().b, r->stream);
+}
+void drain_events(mi355pt_render* r) {
+    for (auto& e : r->events) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, e.a, e.b) == hipSuccess) { r->ms[e.kind] += ms; if (e.kind == 0) r->extend_launches++; }
+        (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b);
+    }
+    r->events.clear();
+}
+
+// The bounce loop for `n` initialised path slots.
+int run_paths(mi355pt_render* r, uint32_t n) {
+    DPaths& P = r->P; const mi355pt_render_params& p = r->prm;
+    const DScene& S = r->scene->d;
+    Params prm{p.seed, p.width, p.height, p.max_bounces, p.rr_start};
+    const size_t nb = p.max_bounces + 2;
+    HIP_TRY(hipMemsetAsync(P.counts, 0, nb * 4, r->stream));
+    HIP_TRY(hipMemsetAsync(P.scounts, 0, nb * 4, r->stream));
+    const int g = grid_for(r, n);
+    for (uint32_t b = 0; b < p.max_bounces; b++) {
+        ev_begin(r, 0);
+        if (r->count_work) hipLaunchKernelGGL(k_extend<true>, dim3(g), dim3(kBlock), 0, r->stream, S, r->cam, P, prm, b, n);
+        else hipLaunchKernelGGL(k_extend<false>, dim3(g), dim3(kBlock), 0, r->stream, S, r->cam, P, prm, b, n);
+        ev_end(r);
+        ev_begin(r, 1);
+        hipLaunchKernelGGL(k_shade, dim3(g), dim3(kBlock), 0, r->stream, S, r->cam, P, prm, b, n);
+        ev_end(r);
+        ev_begin(r, 2);
+        if (r->count_work) hipLaunchKernelGGL(k_connect<true>, dim3(g), dim3(kBlock), 0, r->stream, S, P, b);
+        else hipLaunchKernelGGL(k_connect<false>, dim3(g), dim3(kBlock), 0, r->stream, S, P, b);
+        ev_end(r);
+    }
+    hipLaunchKernelGGL(k_stats, dim3(1), dim3(64), 0, r->stream, P, n, p.max_bounces);
+    HIP_TRY(hipGetLastError());
+    return MI355PT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mi355pt_render_step(mi355pt_render* r, uint32_t spp) {
+    if (!r) return fail(MI355PT_ERR_INVALID, "null renderer");
+    HIP_TRY(hipSetDevice(r->scene->device));
+    const mi355pt_render_params& p = r->prm;
+    const size_t npix = (size_t)p.width * p.height, cap = r->P.cap;
+    const size_t ppc = std::min(npix, cap);
+    const size_t spc = ppc == npix ? std::max<size_t>(1, cap / npix) : 1;
+    const Params kprm{p.seed, p.width, p.height, p.max_bounces, p.rr_start};
+    for (size_t pix_base = 0; pix_base < npix; pix_base += ppc) {
+        const uint32_t np = (uint32_t)std::min(ppc, npix - pix_base);
+        for (uint32_t s0 = 0; s0 < spp; s0 += (uint32_t)spc) {
+            const uint32_t ns = (uint32_t)std::min<size_t>(spc, spp - s0);
+            const uint32_t n = np * ns;
+            ev_begin(r, 3);
+            hipLaunchKernelGGL(k_init, dim3(grid_for(r, n)), dim3(kBlock), 0, r->stream, r->P, kprm,
+                               n, (uint32_t)pix_base, np, r->cnt, p.sample_offset, p.sample_stride, (const uint32_t*)nullptr, (const uint32_t*)nullptr);
+            ev_end(r);
+            if (int rc = run_paths(r, n)) return rc;
+            ev_begin(r, 3);
+            hipLaunchKernelGGL(k_resolve, dim3(grid_for(r, np)), dim3(kBlock), 0, r->stream, r->P, r->mean, r->cnt, r->rgb8, (uint32_t)pix_base, np, ns);
+            ev_end(r);
+        }
+    }
+    HIP_TRY(hipGetLastError());
+    return MI355PT_OK;
+}
+
+int mi355pt_render_sync(mi355pt_render* r) {
+    if (!r) return fail(MI355PT_ERR_INVALID, "null renderer");
+    HIP_TRY(hipSetDevice(r->scene->device));
+    HIP_TRY(hipStreamSynchronize(r->stream));
+    drain_events(r);
+    return MI355PT_OK;
+}
+
+int mi355pt_render_read_rgb8(mi355pt_render* r, uint8_t* rgb) {
+    if (!r || !rgb) return fail(MI355PT_ERR_INVALID, "null argument");
+    if (int rc = mi355pt_render_sync(r)) return rc;
+    HIP_TRY(hipMemcpy(rgb, r->rgb8, (size_t)r->prm.width * r->prm.height * 3, hipMemcpyDeviceToHost));
+    return MI355PT_OK;
+}
+int mi355pt_render_read_accum(mi355pt_render* r, float* mean_rgb, uint32_t* count) {
+    if (!r) return fail(MI355PT_ERR_INVALID, "null argument");
+    if (int rc = mi355pt_render_sync(r)) return rc;
+    const size_t npix = (size_t)r->prm.width * r->prm.height;
+    if (mean_rgb) HIP_TRY(hipMemcpy(mean_rgb, r->mean, npix * 12, hipMemcpyDeviceToHost));
+    if (count) HIP_TRY(hipMemcpy(count, r->cnt, npix * 4, hipMemcpyDeviceToHost));
+    return MI355PT_OK;
+}
+int mi355pt_render_write_accum(mi355pt_render* r, const float* mean_rgb, const uint32_t* count) {
+    if (!r) return fail(MI355PT_ERR_INVALID, "null argument");
+    if (int rc = mi355pt_render_sync(r)) return rc;
+    const size_t npix = (size_t)r->prm.width * r->prm.height;
+    if (mean_rgb) HIP_TRY(hipMemcpy(r->mean, mean_rgb, npix * 12, hipMemcpyHostToDevice));
+    if (count) HIP_TRY(hipMemcpy(r->cnt, count, npix * 4, hipMemcpyHostToDevice));
+    return MI355PT_OK;
+}
+int mi355pt_render_accum_device_ptrs(mi355pt_render* r, void** mean_rgb, void** count) {
+    if (!r) return fail(MI355PT_ERR_INVALID, "null argument");
+    if (mean_rgb) *mean_rgb = r->mean;
+    if (count) *count = r->cnt;
+    return MI355PT_OK;
+}
+
+int mi355pt_trace_primary(mi355pt_render* r, uint32_t x0, uint32_t y0, uint32_t x1, uint32_t y1, int32_t* node, int32_t* mesh, int32_t* face, float* t) {
+    if (!r || !node || !mesh || !face || !t) return fail(MI355PT_ERR_INVALID, "null argument");
+    if (x1 <= x0 || y1 <= y0 || x1 > r->prm.width || y1 > r->prm.height) return fail(MI355PT_ERR_INVALID, "bad rectangle");
+    HIP_TRY(hipSetDevice(r->scene->device));
+    const uint32_t rw = x1 - x0, rh = y1 - y0; const size_t n = (size_t)rw * rh;
+    int32_t *dn, *dm, *df; float* dt;
+    HIP_TRY(hipMalloc((void**)&dn, n * 4)); HIP_TRY(hipMalloc((void**)&dm, n * 4)); HIP_TRY(hipMalloc((void**)&df, n * 4)); HIP_TRY(hipMalloc((void**)&dt, n * 4));
+    const mi355pt_render_params& p = r->prm;
+    Params prm{p.seed, p.width, p.height, p.max_bounces, p.rr_start};
+    if (r->count_work) hipLaunchKernelGGL(k_primary<true>, dim3(grid_for(r, n)), dim3(kBlock), 0, r->stream, r->scene->d, r->cam, prm, x0, y0, rw, rh, dn, dm, df, dt, r->P.stat);
+    else hipLaunchKernelGGL(k_primary<false>, dim3(grid_for(r, n)), dim3(kBlock), 0, r->stream, r->scene->d, r->cam, prm, x0, y0, rw, rh, dn, dm, df, dt, r->P.stat);
+    hipError_t e = hipStreamSynchronize(r->stream);
+    if (e == hipSuccess) e = hipMemcpy(node, dn, n * 4, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(mesh, dm, n * 4, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(face, df, n * 4, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(t, dt, n * 4, hipMemcpyDeviceToHost);
+    (void)hipFree(dn); (void)hipFree(dm); (void)hipFree(df); (void)hipFree(dt);
+    HIP_TRY(e);
+    return MI355PT_OK;
+}
+
+int mi355pt_sample_radiance(mi355pt_render* r, const uint32_t* pixel, const uint32_t* sample, uint32_t count, float* linear_rgb, float* mapped_rgb) {
+    if (!r || !pixel || !sample) return fail(MI355PT_ERR_INVALID, "null argument");
+    if (count == 0) return MI355PT_OK;
+    if (count > r->P.cap) return fail(MI355PT_ERR_TOO_LARGE, "more samples than path slots");
+    const size_t npix = (size_t)r->prm.width * r->prm.height;
+    for (uint32_t i = 0; i < count; i++) if (pixel[i] >= npix) return fail(MI355PT_ERR_INVALID, "pixel index out of range");
+    HIP_TRY(hipSetDevice(r->scene->device));
+    uint32_t *dp, *ds; float *dl, *dm;
+    HIP_TRY(hipMalloc((void**)&dp, (size_t)count * 4)); HIP_TRY(hipMalloc((void**)&ds, (size_t)count * 4));
+    HIP_TRY(hipMalloc((void**)&dl, (size_t)count * 12)); HIP_TRY(hipMalloc((void**)&dm, (size_t)count * 12));
+    HIP_TRY(hipMemcpy(dp, pixel, (size_t)count * 4, hipMemcpyHostToDevice)); HIP_TRY(hipMemcpy(ds, sample, (size_t)count * 4, hipMemcpyHostToDevice));
+    const mi355pt_render_params& p = r->prm;
+    const Params kprm{p.seed, p.width, p.height, p.max_bounces, p.rr_start};
+    hipLaunchKernelGGL(k_init, dim3(grid_for(r, count)), dim3(kBlock), 0, r->stream, r->P, kprm,
+                       count, 0u, 1u, (const uint32_t*)r->cnt, 0u, 1u, (const uint32_t*)dp, (const uint32_t*)ds);
+    int rc = run_paths(r, count);
+    hipLaunchKernelGGL(k_gather, dim3(grid_for(r, count)), dim3(kBlock), 0, r->stream, r->P, count, dl, dm);
+    hipError_t e = hipStreamSynchronize(r->stream);
+    if (e == hipSuccess && linear_rgb) e = hipMemcpy(linear_rgb, dl, (size_t)count * 12, hipMemcpyDeviceToHost);
+    if (e == hipSuccess && mapped_rgb) e = hipMemcpy(mapped_rgb, dm, (size_t)count * 12, hipMemcpyDeviceToHost);
+    (void)hipFree(dp); (void)hipFree(ds); (void)hipFree(dl); (void)hipFree(dm);
+    drain_events(r);
+    if (rc) return rc;
+    HIP_TRY(e);
+    return MI355PT_OK;
+}
+
+int mi355pt_render_stats(mi355pt_render* r, mi355pt_stats* st) {
+    if (!r || !st) return fail(MI355PT_ERR_INVALID, "null argument");
+    if (int rc = mi355pt_render_sync(r)) return rc;
+    unsigned long long h[8];
+    HIP_TRY(hipMemcpy(h, r->P.stat, sizeof(h), hipMemcpyDeviceToHost));
+    st->closest_rays = h[0]; st->shadow_rays = h[1]; st->samples = h[2]; st->bvh_node_visits = h[3]; st->bvh_tri_tests = h[4];
+    st->extend_ms = r->ms[0]; st->shade_ms = r->ms[1]; st->connect_ms = r->ms[2]; st->other_ms = r->ms[3];
+    st->extend_launches = r->extend_launches;
+    return MI355PT_OK;
+}
+int mi355pt_render_reset_stats(mi355pt_render* r) {
+    if (!r) return fail(MI355PT_ERR_INVALID, "null argument");
+    if (int rc = mi355pt_render_sync(r)) return rc;
+    HIP_TRY(hipMemset(r->P.stat, 0, 8 * sizeof(unsigned long long)));
+    for (double& m : r->ms) m = 0;
+    r->extend_launches = 0;
+    return MI355PT_OK;
+}
+int mi355pt_render_set_profiling(mi355pt_render* r, int enable_events, int count_work) {
+    if (!r) return fail(MI355PT_ERR_INVALID, "null argument");
+    if (int rc = mi355pt_render_sync(r)) return rc;
+    r->profiling = enable_events != 0; r->count_work = count_work != 0;
+    return MI355PT_OK;
+}
+void* mi355pt_render_stream(mi355pt_render* r) { return r ? (void*)r->stream : nullptr; }
+
+}  // extern "C"

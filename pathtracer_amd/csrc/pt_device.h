@@ -1,0 +1,362 @@
+// pt_device.h -- device-side arithmetic of the hot path (product code, gfx950).
+//
+// Every routine restates the fp32 expression trees of the reference function it names
+// (compile with -ffp-contract=off; IEEE divide/sqrt are hipcc's default), but on the
+// flattened scene of pt_scene.h: no virtual calls, no HitInfo copies, attribute
+// interpolation only for the winning primitive.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "pt_scene.h"
+
+#define PT_DEV __device__ __forceinline__
+
+namespace ptd {
+
+constexpr float kPI = 3.1415926535897932384626433f;       // reference include/constants.h:5-9
+constexpr float kTwoPI = kPI * 2.0f;
+constexpr float kInvPI = 1.0f / kPI;
+constexpr float kBig = 1.0e30f;
+constexpr float kBias = 0.0001f;
+constexpr float kFltEps = 1.1920928955078125e-7f;
+enum { SIDE_FRONT = 1, SIDE_BACK = 2, SIDE_BOTH = 3 };
+
+// ------------------------------------------------------------------ vectors (cyVector.h semantics)
+struct F3 { float x, y, z; };
+struct F2 { float x, y; };
+PT_DEV F3 f3(float x, float y, float z) { F3 r; r.x = x; r.y = y; r.z = z; return r; }
+PT_DEV F3 ld3(const float* p) { return f3(p[0], p[1], p[2]); }
+PT_DEV F3 operator+(F3 a, F3 b) { return f3(a.x + b.x, a.y + b.y, a.z + b.z); }
+PT_DEV F3 operator-(F3 a, F3 b) { return f3(a.x - b.x, a.y - b.y, a.z - b.z); }
+PT_DEV F3 operator*(F3 a, F3 b) { return f3(a.x * b.x, a.y * b.y, a.z * b.z); }
+PT_DEV F3 operator/(F3 a, F3 b) { return f3(a.x / b.x, a.y / b.y, a.z / b.z); }
+PT_DEV F3 operator+(F3 a, float v) { return f3(a.x + v, a.y + v, a.z + v); }
+PT_DEV F3 operator-(F3 a, float v) { return f3(a.x - v, a.y - v, a.z - v); }
+PT_DEV F3 operator*(F3 a, float v) { return f3(a.x * v, a.y * v, a.z * v); }
+PT_DEV F3 operator*(float v, F3 a) { return f3(a.x * v, a.y * v, a.z * v); }
+PT_DEV F3 operator/(F3 a, float v) { return f3(a.x / v, a.y / v, a.z / v); }
+PT_DEV F3 neg(F3 a) { return f3(-a.x, -a.y, -a.z); }
+PT_DEV float dot(F3 a, F3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+PT_DEV F3 cross(F3 a, F3 p) { return f3(a.y * p.z - a.z * p.y, a.z * p.x - a.x * p.z, a.x * p.y - a.y * p.x); }
+PT_DEV float len2(F3 a) { return a.x * a.x + a.y * a.y + a.z * a.z; }
+PT_DEV float len(F3 a) { return sqrtf(len2(a)); }
+PT_DEV F3 normalized(F3 a) { return a / len(a); }
+PT_DEV float max3(F3 a) { return a.x > a.y ? (a.x > a.z ? a.x : a.z) : (a.y > a.z ? a.y : a.z); }
+PT_DEV float sum3(F3 a) { return a.x + a.y + a.z; }
+PT_DEV float cymax(float a, float b) { return a >= b ? a : b; }
+PT_DEV F2 f2(float x, float y) { F2 r; r.x = x; r.y = y; return r; }
+PT_DEV F2 operator-(F2 a, F2 b) { return f2(a.x - b.x, a.y - b.y); }
+PT_DEV float cross2(F2 a, F2 p) { return (-a.y) * p.x + a.x * p.y; }
+
+// Matrix3 * Vec3 (cyMatrix.h:684-688), column-major cells
+PT_DEV F3 m3mul(const float* c, F3 p) {
+    return f3(p.x * c[0] + p.y * c[3] + p.z * c[6], p.x * c[1] + p.y * c[4] + p.z * c[7], p.x * c[2] + p.y * c[5] + p.z * c[8]);
+}
+// TransposeMult (Transformation.h:87-94)
+PT_DEV F3 m3tmul(const float* c, F3 d) {
+    return f3(c[0] * d.x + c[1] * d.y + c[2] * d.z, c[3] * d.x + c[4] * d.y + c[5] * d.z, c[6] * d.x + c[7] * d.y + c[8] * d.z);
+}
+// Matrix4 * Vec4(p, w) -> xyz (cyMatrix.h:1941-1957: (x*c0 + z*c8) + (y*c4 + w*c12))
+PT_DEV F3 m4mulp(const float* c, F3 p, float w) {
+    return f3((p.x * c[0] + p.z * c[8]) + (p.y * c[4] + w * c[12]),
+              (p.x * c[1] + p.z * c[9]) + (p.y * c[5] + w * c[13]),
+              (p.x * c[2] + p.z * c[10]) + (p.y * c[6] + w * c[14]));
+}
+
+// ------------------------------------------------------------------ RNG (specification in DESIGN.md)
+PT_DEV uint32_t fmix32(uint32_t h) { h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16; return h; }
+struct Rng {
+    uint32_t key;      // hash of (seed, pixel, sample)
+    uint32_t draw;
+    PT_DEV void init(uint32_t seed, uint32_t pixel, uint32_t sample, uint32_t d) {
+        uint32_t h = fmix32(seed + 0x9E3779B9u);
+        h = fmix32(h ^ (pixel + 0x7F4A7C15u));
+        key = fmix32(h ^ (sample * 0x85EBCA77u + 0xC2B2AE3Du));
+        draw = d;
+    }
+    PT_DEV int next() { uint32_t h = fmix32(key ^ (draw * 0x27D4EB2Fu + 0x165667B1u)); draw++; return (int)(h >> 1); }
+    PT_DEV float U() { return (float)next() / 2147483648.0f; }       // rand() / (float)RAND_MAX
+};
+constexpr uint32_t kPixelOffsetSample = 0xFFFFFFFFu;
+
+// ------------------------------------------------------------------ rays / camera
+struct Ray { F3 p, d; };
+
+// src/utils.cpp:67-79 + src/raytracer.cpp:272-316 + src/sampler.cpp:15-32
+PT_DEV float halton(int index, int base) {      // include/scene.h:62-71
+    float r = 0;
+    float f = 1.0f / (float)base;
+    for (int i = index; i > 0; i /= base) { r += f * (i % base); f /= (float)base; }
+    return r;
+}
+// Camera ray context of (pixel, sample).  jitter == false gives GenCameraRayContext(x, y, 0, 0).
+PT_DEV void camera_rays(const DCamera& c, uint32_t seed, uint32_t pixel, uint32_t sample, uint32_t width, bool jitter,
+                        Ray& mainRay, F3& rightDir, F3& topDir) {
+    const int y = (int)(pixel / width), x = (int)(pixel - (uint32_t)y * width);
+    float finalX = 0.0f, finalY = 0.0f;
+    if (jitter) {
+        Rng po; po.init(seed, pixel, kPixelOffsetSample, 0);      // PixelContext ctor draws (pathtracer.h:15-19)
+        const float offx = po.U(), offy = po.U();
+        finalX = (halton((int)sample, 2) - 0.5f) + offx;
+        if (finalX >= 0.5f) finalX -= 1.0f;
+        finalY = (halton((int)sample, 3) - 0.5f) + offy;
+        if (finalY >= 0.5f) finalY -= 1.0f;
+    }
+    Rng rng; rng.init(seed, pixel, sample, 0);
+    const float S = rng.U();
+    const float r = sqrtf(S) * c.dof;
+    const float theta = rng.U() * kTwoPI;
+    const float lx = r * cosf(theta), ly = r * sinf(theta);
+    const F3 right = ld3(c.right), up = ld3(c.up), front = ld3(c.front);
+    const F3 lens = right * lx + up * ly;
+    mainRay.p = ld3(c.pos) + right * lx + up * ly;
+    F3 dir = (right * (-1.0f * c.plane_w * 0.5f + (float)x * c.texel_w + 0.5f * c.texel_w + finalX * c.texel_w) +
+              up * (c.plane_h * 0.5f - (float)y * c.texel_h - 0.5f * c.texel_h - finalY * c.texel_h) +
+              front * c.focaldist) - lens;
+    rightDir = normalized(dir + right * c.texel_w * 1.0f);
+    topDir = normalized(dir + up * c.texel_h * 1.0f);
+    mainRay.d = dir / len(dir);
+}
+
+// ------------------------------------------------------------------ node transforms (node.h:174-201)
+PT_DEV Ray to_node(const DNodeXf& n, const Ray& r) {
+    const F3 pos = ld3(n.pos);
+    Ray o;
+    o.p = m3mul(n.itm, r.p - pos);
+    o.d = m3mul(n.itm, (r.p + r.d) - pos) - o.p;
+    return o;
+}
+PT_DEV Ray to_inst(const DScene& S, const DInst& in, Ray r) {
+    for (int i = 0; i < in.chain_len; i++) r = to_node(S.nodes[in.chain[i]], r);
+    return r;
+}
+
+// ------------------------------------------------------------------ slab test (bvh.h:88-129, scene.cpp:3-40)
+// inv = 1/dir is computed once per (ray, instance): same values as the reference's per-call division.
+PT_DEV bool slab(const float* b, F3 p, F3 inv, float& tnear) {
+    const bool s0 = inv.x < 0, s1 = inv.y < 0, s2 = inv.z < 0;
+    float tmin = ((s0 ? b[3] : b[0]) - p.x) * inv.x;
+    float tmax = ((s0 ? b[0] : b[3]) - p.x) * inv.x;
+    const float tymin = ((s1 ? b[4] : b[1]) - p.y) * inv.y;
+    const float tymax = ((s1 ? b[1] : b[4]) - p.y) * inv.y;
+    if ((tmin > tymax) || (tymin > tmax)) return false;
+    if (tymin > tmin) tmin = tymin;
+    if (tymax < tmax) tmax = tymax;
+    const float tzmin = ((s2 ? b[5] : b[2]) - p.z) * inv.z;
+    const float tzmax = ((s2 ? b[2] : b[5]) - p.z) * inv.z;
+    if ((tmin > tzmax) || (tzmin > tmax)) return false;
+    if (tzmin > tmin) tmin = tzmin;
+    tnear = tmin;
+    return true;
+}
+
+// ------------------------------------------------------------------ triangle (model.h:227-347)
+struct Tri { F3 v0, v1, v2; uint32_t face; };
+PT_DEV Tri load_tri(const float4* tris, uint32_t slot) {
+    const float4 a = tris[3 * (size_t)slot], b = tris[3 * (size_t)slot + 1], c = tris[3 * (size_t)slot + 2];
+    Tri t;
+    t.v0 = f3(a.x, a.y, a.z); t.v1 = f3(a.w, b.x, b.y); t.v2 = f3(b.z, b.w, c.x);
+    t.face = __float_as_uint(c.y);
+    return t;
+}
+// glm arithmetic (func_geometric.inl:48-54,68-79; func_matrix.inl:269-291; type_mat3x3.inl:467-474)
+PT_DEV float gdot(F3 a, F3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+PT_DEV F3 gcross(F3 x, F3 y) { return f3(x.y * y.z - y.y * x.z, x.z * y.x - y.z * x.x, x.x * y.y - y.x * x.y); }
+PT_DEV F3 gnormalize(F3 v) { return v * (1.0f / sqrtf(gdot(v, v))); }
+
+// Barycentric part of IntersectRayWithFace for point P and matrix columns (c0, v01, v02);
+// GLM = true uses glm::inverse (one reciprocal), false uses cy Matrix3::Invert (divide by det).
+template <bool GLM>
+PT_DEV void tri_areas(F3 c0, F3 v01, F3 v02, F3 v0, F3 v1, F3 v2, F3 P, float& a0, float& a1, float& a2, float& a) {
+    // m[col][row]: m0 = c0, m1 = v01, m2 = v02.  Only rows y,z of the inverse are used.
+    float i01, i11, i21, i02, i12, i22;      // inverse[col][row] for rows 1,2
+    if (GLM) {
+        const float ood = 1.0f / (+c0.x * (v01.y * v02.z - v02.y * v01.z) - v01.x * (c0.y * v02.z - v02.y * c0.z) + v02.x * (c0.y * v01.z - v01.y * c0.z));
+        i01 = -(c0.y * v02.z - v02.y * c0.z) * ood;
+        i11 = +(c0.x * v02.z - v02.x * c0.z) * ood;
+        i21 = -(c0.x * v02.y - v02.x * c0.y) * ood;
+        i02 = +(c0.y * v01.z - v01.y * c0.z) * ood;
+        i12 = -(c0.x * v01.z - v01.x * c0.z) * ood;
+        i22 = +(c0.x * v01.y - v01.x * c0.y) * ood;
+    } else {
+        // cyMatrix.h:799-820 with cell[0..2]=c0, [3..5]=v01, [6..8]=v02; inverse cell[1],[4],[7] = row 1, [2],[5],[8] = row 2
+        const float n0 = (v01.y * v02.z - v01.z * v02.y);
+        const float n3 = (v01.z * v02.x - v01.x * v02.z);
+        const float n6 = (v01.x * v02.y - v01.y * v02.x);
+        const float det = c0.x * n0 + c0.y * n3 + c0.z * n6;
+        i01 = (c0.z * v02.y - c0.y * v02.z) / det;
+        i11 = (c0.x * v02.z - c0.z * v02.x) / det;
+        i21 = (c0.y * v02.x - c0.x * v02.y) / det;
+        i02 = (c0.y * v01.z - c0.z * v01.y) / det;
+        i12 = (c0.z * v01.x - c0.x * v01.z) / det;
+        i22 = (c0.x * v01.y - c0.y * v01.x) / det;
+    }
+    // rows y,z of M^-1 * v.  glm: m[0][r]*v.x + m[1][r]*v.y + m[2][r]*v.z; cy: p.x*cell[r] + p.y*cell[3+r] + p.z*cell[6+r]
+    // (same products, same order; cy multiplies v.x*cell, glm cell*v.x: commutative)
+#define PT_ROW1(v) (i01 * (v).x + i11 * (v).y + i21 * (v).z)
+#define PT_ROW2(v) (i02 * (v).x + i12 * (v).y + i22 * (v).z)
+    const F2 q0 = f2(PT_ROW1(v0), PT_ROW2(v0)), q1 = f2(PT_ROW1(v1), PT_ROW2(v1)), q2 = f2(PT_ROW1(v2), PT_ROW2(v2)), qp = f2(PT_ROW1(P), PT_ROW2(P));
+#undef PT_ROW1
+#undef PT_ROW2
+    const F2 pv0 = q0 - qp, pv1 = q1 - qp, pv2 = q2 - qp;
+    a0 = cross2(pv1, pv2); a1 = cross2(pv2, pv0); a2 = cross2(pv0, pv1);
+    a = cross2(q1 - q0, q2 - q0);
+}
+
+// Closest-hit candidate test.  (bt, bslot) is the current best in (t, slot) order; the slot order
+// IS the reference's tie-break order (bvh_build.h).  Returns true when the candidate replaces it.
+// The early exit before the matrix inverse cannot change the outcome: a candidate that is not
+// better in (t, slot) would be discarded anyway.
+PT_DEV bool tri_closest(const Tri& T, F3 o, F3 d, int side, uint32_t slot, float& bt, uint32_t& bslot) {
+    const F3 v01 = T.v1 - T.v0, v02 = T.v2 - T.v0;
+    const F3 n = gcross(v01, v02);
+    const float dn = gdot(d, n);
+    if (fabsf(dn) <= kFltEps) return false;
+    const float t = (gdot(T.v0, n) - gdot(o, n)) / dn;
+    if (t < 0.0f) return false;
+    const bool front = dn < 0.0f;
+    if (side == SIDE_FRONT && !front) return false;
+    if (side == SIDE_BACK && front) return false;
+    if (!(t < bt || (t == bt && slot < bslot))) return false;
+    const F3 P = o + d * t;
+    float a0, a1, a2, a;
+    tri_areas<true>(neg(d), v01, v02, T.v0, T.v1, T.v2, P, a0, a1, a2, a);
+    if (a0 <= 0.0f) return false;
+    if (a1 <= 0.0f) return false;
+    if (a2 <= 0.0f) return false;
+    bt = t; bslot = slot;
+    return true;
+}
+// Any-hit form for visibility (raytracer.cpp:99-130): front faces only, accepted iff t < bound.
+PT_DEV bool tri_any_front(const Tri& T, F3 o, F3 d, float bound) {
+    const F3 v01 = T.v1 - T.v0, v02 = T.v2 - T.v0;
+    const F3 n = gcross(v01, v02);
+    const float dn = gdot(d, n);
+    if (fabsf(dn) <= kFltEps) return false;
+    const float t = (gdot(T.v0, n) - gdot(o, n)) / dn;
+    if (t < 0.0f) return false;
+    if (!(dn < 0.0f)) return false;
+    if (!(t < bound)) return false;
+    const F3 P = o + d * t;
+    float a0, a1, a2, a;
+    tri_areas<true>(neg(d), v01, v02, T.v0, T.v1, T.v2, P, a0, a1, a2, a);
+    return a0 > 0.0f && a1 > 0.0f && a2 > 0.0f;
+}
+
+// ------------------------------------------------------------------ BVH traversal
+// Ordered, pruned walk over the flattened tree (layout: bvh_build.h).  Reference semantics kept:
+// a node's bound is tested only when the node is internal; leaf faces are all tested; the result
+// is the minimum in (t, slot) order == the reference's exhaustive recursion with its tie rules
+// (src/model.cpp:4-163).  Pruning uses the slab entry distance against the running best.
+constexpr int kStackSize = 64;
+struct WorkCounters { uint32_t nodes, tris; };
+
+template <bool ANY, bool COUNT>
+PT_DEV bool traverse_mesh(const DScene& S, const DMesh& M, F3 o, F3 d, F3 inv, int side, float& bt, uint32_t& bslot, WorkCounters& wc) {
+    // ANY: bt is the (fixed) bound; returns true on the first accepted front-face hit.
+    // !ANY: (bt, bslot) updated; returns true if it changed.
+    bool changed = false;
+    uint32_t stack_n[kStackSize];
+    float stack_t[kStackSize];
+    int sp = 0;
+    uint32_t leaf_first[2]; uint32_t leaf_cnt[2]; int nleaf = 0;
+    if (M.root_cnt == 0xFFFFFFFFu) {
+        float tn;
+        if (COUNT) wc.nodes++;
+        if (!slab(M.root_bound, o, inv, tn)) return false;
+        stack_n[sp] = M.root_ref; stack_t[sp] = -kBig; sp++;
+    } else {
+        leaf_first[0] = M.root_ref; leaf_cnt[0] = M.root_cnt; nleaf = 1;
+    }
+    for (;;) {
+        for (int l = 0; l < nleaf; l++) {
+            for (uint32_t k = 0; k < leaf_cnt[l]; k++) {
+                const uint32_t slot = leaf_first[l] + k;
+                const Tri T = load_tri(S.tris, slot);
+                if (COUNT) wc.tris++;
+                if (ANY) { if (tri_any_front(T, o, d, bt)) return true; }
+                else changed |= tri_closest(T, o, d, side, slot, bt, bslot);
+            }
+        }
+        nleaf = 0;
+        if (sp == 0) break;
+        sp--;
+        const uint32_t ni = stack_n[sp];
+        if (stack_t[sp] > bt) continue;          // pruned by a hit found since the push
+        const float4* np = S.bvh_nodes + 4 * (size_t)ni;
+        const float4 w0 = np[0], w1 = np[1], w2 = np[2], w3 = np[3];
+        if (COUNT) wc.nodes++;
+        const float lb[6] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y};
+        const float rb[6] = {w1.z, w1.w, w2.x, w2.y, w2.z, w2.w};
+        const uint32_t lref = __float_as_uint(w3.x), rref = __float_as_uint(w3.y), lcnt = __float_as_uint(w3.z), rcnt = __float_as_uint(w3.w);
+        float tl = -kBig, tr = -kBig;
+        bool hl = true, hr = true;
+        if (lcnt == 0xFFFFFFFFu) { hl = slab(lb, o, inv, tl); if (tl > bt) hl = false; }
+        else { leaf_first[nleaf] = lref; leaf_cnt[nleaf] = lcnt; nleaf++; hl = false; }
+        if (rcnt == 0xFFFFFFFFu) { hr = slab(rb, o, inv, tr); if (tr > bt) hr = false; }
+        else { leaf_first[nleaf] = rref; leaf_cnt[nleaf] = rcnt; nleaf++; hr = false; }
+        if (hl && hr) {
+            const bool left_first = !(tr < tl);
+            if (sp + 2 <= kStackSize) {
+                if (left_first) { stack_n[sp] = rref; stack_t[sp] = tr; sp++; stack_n[sp] = lref; stack_t[sp] = tl; sp++; }
+                else { stack_n[sp] = lref; stack_t[sp] = tl; sp++; stack_n[sp] = rref; stack_t[sp] = tr; sp++; }
+            }
+        } else if (hl) { if (sp < kStackSize) { stack_n[sp] = lref; stack_t[sp] = tl; sp++; } }
+        else if (hr) { if (sp < kStackSize) { stack_n[sp] = rref; stack_t[sp] = tr; sp++; } }
+    }
+    return ANY ? false : changed;
+}
+
+// ------------------------------------------------------------------ plane (objects.cpp:560-614)
+PT_DEV bool plane_hit(F3 o, F3 d, int side, float& t, bool& front, F3& P) {
+    const float dn = d.z;                       // dir . (0,0,1)
+    if (fabsf(dn - 0.0f) < 0.000001f) return false;
+    const float tt = -1.0f * (o.z / dn);
+    if (tt <= 0.0f) return false;
+    const F3 p = o + d * tt;
+    if (fabsf(p.x) >= 1.0f) return false;
+    if (fabsf(p.y) >= 1.0f) return false;
+    const bool f = dn < 0.0f;
+    if (side == SIDE_FRONT && !f) return false;
+    if (side == SIDE_BACK && f) return false;
+    t = tt; front = f; P = p;
+    return true;
+}
+
+// ------------------------------------------------------------------ closest hit over the scene
+// TraceNode (raytracer.cpp:189-258) over the instance table: instances are in the reference's
+// depth-first order and a later instance must be strictly closer to win.
+struct HitRec { float t; int inst; int mesh; uint32_t slot; };
+
+template <bool COUNT>
+PT_DEV HitRec trace_closest(const DScene& S, const Ray& wr, WorkCounters& wc) {
+    HitRec best; best.t = kBig; best.inst = -1; best.mesh = -1; best.slot = 0;
+    for (int ii = 0; ii < S.num_insts; ii++) {
+        const DInst& in = S.insts[ii];
+        const Ray lr = to_inst(S, in, wr);
+        if (in.kind == MI355PT_OBJ_PLANE) {
+            float t; bool front; F3 P;
+            if (plane_hit(lr.p, lr.d, SIDE_BOTH, t, front, P) && t < best.t) { best.t = t; best.inst = ii; best.mesh = -1; best.slot = 0; }
+        } else if (in.kind == MI355PT_OBJ_MODEL) {
+            const DModel& mo = S.models[in.model];
+            const F3 inv = f3(1.0f, 1.0f, 1.0f) / lr.d;
+            float tn;
+            if (!slab(mo.aabb, lr.p, inv, tn)) continue;
+            for (int mi = 0; mi < mo.num_meshes; mi++) {
+                const DMesh& M = S.meshes[mo.first_mesh + mi];
+                if (!slab(M.aabb, lr.p, inv, tn)) continue;
+                // Start from the global best with bslot = 0: no slot is < 0, so a candidate with
+                // t == best.t loses (the earlier object wins ties, raytracer.cpp:208,238 / model.cpp:237)
+                // and only a strictly closer one replaces it.
+                float bt = best.t; uint32_t bslot = 0;
+                bool ch;
+                ch = traverse_mesh<false, COUNT>(S, M, lr.p, lr.d, inv, SIDE_BOTH, bt, bslot, wc);
+                if (ch) { best.t = bt; best.inst = ii; best.mesh = mi; best.slot = bslot; }
+            }
+        }
+    }
+    return best;
+}
+
+}  // namespace ptd

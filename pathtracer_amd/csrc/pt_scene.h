@@ -1,0 +1,55 @@
+// pt_scene.h -- the flattened scene as the kernels see it in HBM (product code).
+// Layout rationale in DESIGN.md ("Data layout in HBM").
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/mi355pt.h"
+
+namespace ptd {
+
+struct DNodeXf {                 // one scene-graph node (reference Transformation + Node)
+    float tm[9], itm[9], pos[3];
+    float l2w[16];
+    int   material, light, pad0, pad1;
+};
+struct DInst {                   // one object-bearing node, in the reference's depth-first order
+    int node, kind, model, chain_len;
+    int chain[MI355PT_MAX_CHAIN];    // node indices root -> node
+};
+struct DModel { float aabb[6]; int first_mesh, num_meshes; };
+struct DMesh {
+    float    aabb[6];
+    float    root_bound[6];
+    uint32_t root_ref, root_cnt;     // encoding of bvh_build.h
+    uint32_t face_base;              // offset (in faces) into DScene::faces
+    uint32_t vert_base;              // offset (in vertices) into normals / uvw
+    uint32_t has_tangents, pad;
+};
+struct DTexture { int kind, width, height, pad; const void* data; float c1[3], c2[3]; };
+struct DLight { int node; float intensity[3]; float area; int inst; int pad0, pad1; };
+struct DCamera {
+    float pos[3], up[3], front[3], right[3];
+    float plane_h, plane_w, texel_w, texel_h, focaldist, dof;
+};
+
+struct DScene {
+    const DNodeXf*  nodes;      int num_nodes;
+    const DInst*    insts;      int num_insts;
+    const DModel*   models;
+    const DMesh*    meshes;
+    const float4*   bvh_nodes;       // 4 x float4 (64 B) per internal node, all meshes
+    const float4*   tris;            // 3 x float4 (48 B) per triangle slot: v0 v1 v2 faceId
+    const uint32_t* faces;           // 4 per face: i0 i1 i2 faceId (mesh-local vertex indices)
+    const float*    normals;         // 3 per vertex
+    const float*    uvw;             // 3 per vertex
+    const float*    tangents;        // 3 per face (indexed face_base + faceId)
+    const float*    bitangents;
+    const mi355pt_material* materials;
+    const mi355pt_texmap*   texmaps;
+    const DTexture* textures;
+    const DLight*   lights;     int num_lights;
+    float env_color[3];         int env_map;
+};
+
+}  // namespace ptd

@@ -1,0 +1,491 @@
+// pt_shade.h -- device-side shading arithmetic: hit reconstruction, textures, Disney and
+// Cook-Torrance materials, rectangular area light, visibility (product code, gfx950).
+// Reference functions restated are cited at each routine.
+#pragma once
+#include "pt_device.h"
+
+namespace ptd {
+
+// ------------------------------------------------------------------ surface hit (HitInfo, hitinfo.h:23-62)
+struct Surf {
+    float z;
+    F3 p, N, T, B, uvw, du0, du1;
+    int node, mtl;
+    bool front;
+};
+
+// IntersectRayWithFace for the winning triangle only (model.h:227-347 attributes, :90-225 differentials)
+PT_DEV F3 diff_tex(const Ray& dr, F3 pD, const Tri& T, F3 v01, F3 v02, F3 t0, F3 t1, F3 t2) {
+    float a0, a1, a2, a;
+    tri_areas<false>(neg(dr.d), v01, v02, T.v0, T.v1, T.v2, pD, a0, a1, a2, a);
+    const float b0 = a0 / a, b1 = a1 / a, b2 = a2 / a;
+    return b0 * t0 + b1 * t1 + b2 * t2;
+}
+PT_DEV void surf_triangle(const DScene& S, const DMesh& M, uint32_t slot, const Ray& r, bool hasDiff, const Ray& rr, const Ray& tr, Surf& h) {
+    const Tri T = load_tri(S.tris, slot);
+    const F3 v01 = T.v1 - T.v0, v02 = T.v2 - T.v0;
+    const F3 n = gcross(v01, v02);
+    const float dn = gdot(r.d, n);
+    const float t = (gdot(T.v0, n) - gdot(r.p, n)) / dn;
+    const bool front = dn < 0.0f;
+    const F3 P = r.p + r.d * t;
+    float a0, a1, a2, a;
+    tri_areas<true>(neg(r.d), v01, v02, T.v0, T.v1, T.v2, P, a0, a1, a2, a);
+    const float b0 = a0 / a, b1 = a1 / a, b2 = a2 / a;
+    const uint32_t* f = S.faces + 4 * (size_t)(M.face_base + T.face);
+    const float* nb = S.normals + 3 * (size_t)M.vert_base;
+    const float* tb = S.uvw + 3 * (size_t)M.vert_base;
+    const F3 n0 = ld3(nb + 3 * (size_t)f[0]), n1 = ld3(nb + 3 * (size_t)f[1]), n2 = ld3(nb + 3 * (size_t)f[2]);
+    F3 normal = gnormalize(b0 * n0 + b1 * n1 + b2 * n2);
+    const float ns = normal.x + normal.y + normal.z;
+    if (isnan(ns) || isinf(ns)) normal = gnormalize(n);
+    const F3 t0 = ld3(tb + 3 * (size_t)f[0]), t1 = ld3(tb + 3 * (size_t)f[1]), t2 = ld3(tb + 3 * (size_t)f[2]);
+    h.T = f3(0, 0, 0); h.B = f3(0, 0, 0);
+    if (M.has_tangents) {
+        const size_t fi = (size_t)M.face_base + f[3];
+        h.T = ld3(S.tangents + 3 * fi); h.B = ld3(S.bitangents + 3 * fi);
+    }
+    h.p = P; h.z = t; h.front = front;
+    h.N = front ? normal : -1.0f * normal;
+    h.uvw = b0 * t0 + b1 * t1 + b2 * t2;
+    if (hasDiff) {
+        const F3 N = normalized(h.N);
+        const float tR = dot(rr.p - h.p, N) / dot(rr.d, N);
+        const F3 pR = rr.p + tR * rr.d;
+        const float tT = dot(tr.p - h.p, N) / dot(tr.d, N);
+        const F3 pT = tr.p + tT * tr.d;
+        const F3 texR = diff_tex(rr, pR, T, v01, v02, t0, t1, t2);
+        const F3 texT = diff_tex(tr, pT, T, v01, v02, t0, t1, t2);
+        h.du0 = (texR - h.uvw) / 1.0f;
+        h.du1 = (texT - h.uvw) / 1.0f;
+    } else { h.du0 = f3(0, 0, 0); h.du1 = f3(0, 0, 0); }
+}
+// Plane::IntersectRay (objects.cpp:505-614)
+PT_DEV F3 plane_tex(F3 p) { return p * 0.5f + f3(0.5f, 0.5f, 0.0f); }
+PT_DEV void surf_plane(const Ray& r, bool hasDiff, const Ray& rr, const Ray& tr, Surf& h) {
+    float t; bool front; F3 P;
+    plane_hit(r.p, r.d, SIDE_BOTH, t, front, P);
+    const F3 n = f3(0.0f, 0.0f, 1.0f);
+    h.front = front; h.N = front ? n : -1.0f * n; h.p = P; h.z = t;
+    h.T = f3(1.0f, 0.0f, 0.0f); h.B = f3(0.0f, 1.0f, 0.0f);
+    h.uvw = plane_tex(P);
+    if (hasDiff) {
+        const F3 N = normalized(h.N);
+        const float tR = -1.0f * dot(rr.p, N) / dot(rr.d, N);
+        const F3 pR = rr.p + tR * rr.d;
+        const float tT = -1.0f * dot(tr.p, N) / dot(tr.d, N);
+        const F3 pT = tr.p + tT * tr.d;
+        h.du0 = (plane_tex(pR) - h.uvw) / 1.0f;
+        h.du1 = (plane_tex(pT) - h.uvw) / 1.0f;
+    } else { h.du0 = f3(0, 0, 0); h.du1 = f3(0, 0, 0); }
+}
+// FromNodeCoords up the chain (node.h:195-201), as TraceNode applies it level by level
+PT_DEV void surf_to_world(const DScene& S, const DInst& in, Surf& h) {
+    for (int i = in.chain_len - 1; i >= 0; i--) {
+        const DNodeXf& n = S.nodes[in.chain[i]];
+        h.p = m3mul(n.tm, h.p) + ld3(n.pos);
+        h.N = normalized(m3tmul(n.itm, h.N));
+        h.T = normalized(m3tmul(n.itm, h.T));
+        h.B = normalized(m3tmul(n.itm, h.B));
+    }
+}
+// Full HitInfo of a recorded closest hit.
+PT_DEV void surf_from_hit(const DScene& S, const HitRec& hr, const Ray& wr, bool hasDiff, F3 rightDir, F3 topDir, Surf& h) {
+    const DInst& in = S.insts[hr.inst];
+    Ray r = wr, rr, tr;
+    rr.p = wr.p; rr.d = rightDir; tr.p = wr.p; tr.d = topDir;
+    for (int i = 0; i < in.chain_len; i++) {
+        const DNodeXf& n = S.nodes[in.chain[i]];
+        r = to_node(n, r);
+        if (hasDiff) { rr = to_node(n, rr); tr = to_node(n, tr); }
+    }
+    if (in.kind == MI355PT_OBJ_PLANE) surf_plane(r, hasDiff, rr, tr, h);
+    else surf_triangle(S, S.meshes[S.models[in.model].first_mesh + hr.mesh], hr.slot, r, hasDiff, rr, tr, h);
+    surf_to_world(S, in, h);
+    h.node = in.node;
+    h.mtl = S.nodes[in.node].material;
+}
+
+// ------------------------------------------------------------------ textures (scene.h:157-309, texture.cpp:102-150)
+PT_DEV F3 tile_clamp(F3 uvw) {
+    F3 u;
+    u.x = uvw.x - (int)uvw.x; u.y = uvw.y - (int)uvw.y; u.z = uvw.z - (int)uvw.z;
+    if (u.x < 0) u.x += 1;
+    if (u.y < 0) u.y += 1;
+    if (u.z < 0) u.z += 1;
+    return u;
+}
+PT_DEV F3 texel(const DTexture& t, int y, int x) {
+    const size_t i = (size_t)y * t.width + x;
+    if (t.kind == MI355PT_TEX_RGB32F) { const float4 v = ((const float4*)t.data)[i]; return f3(v.x, v.y, v.z); }
+    const uchar4 v = ((const uchar4*)t.data)[i];
+    return f3(v.x / 255.0f, v.y / 255.0f, v.z / 255.0f);
+}
+PT_DEV F3 tex_point(const DTexture& t, F3 uvw) {
+    if (t.kind == MI355PT_TEX_CHECKER) {
+        const F3 u = tile_clamp(uvw);
+        if (u.x <= 0.5f) return u.y <= 0.5f ? ld3(t.c1) : ld3(t.c2);
+        return u.y <= 0.5f ? ld3(t.c2) : ld3(t.c1);
+    }
+    const int width = t.width, height = t.height;
+    if (width + height == 0) return f3(0, 0, 0);
+    const F3 u = tile_clamp(uvw);
+    const float x = width * u.x, y = height * u.y;
+    int ix = (int)x, iy = (int)y;
+    const float fx = x - ix, fy = y - iy;
+    if (ix < 0) ix -= (ix / width - 1) * width;
+    if (ix >= width) ix -= (ix / width) * width;
+    int ixp = ix + 1; if (ixp >= width) ixp -= width;
+    if (iy < 0) iy -= (iy / height - 1) * height;
+    if (iy >= height) iy -= (iy / height) * height;
+    int iyp = iy + 1; if (iyp >= height) iyp -= height;
+    return texel(t, iy, ix) * ((1 - fx) * (1 - fy)) + texel(t, iy, ixp) * (fx * (1 - fy)) +
+           texel(t, iyp, ix) * ((1 - fx) * fy) + texel(t, iyp, ixp) * (fx * fy);
+}
+PT_DEV F3 tex_filtered(const DScene& S, const DTexture& t, F3 uvw, F3 d0, F3 d1) {
+    F3 c = tex_point(t, uvw);
+    if (len2(d0) + len2(d1) == 0) return c;
+    for (int i = 1; i < 32; i++) {
+        float x = halton(i, 2), y = halton(i, 3);
+        const float r = sqrtf(x) * 0.5f;
+        x = r * sinf(y * kPI * 2);
+        y = r * cosf(y * kPI * 2);
+        c = c + tex_point(t, uvw + x * d0 + y * d1);
+    }
+    return c / 32.0f;
+}
+PT_DEV F3 texmap_sample(const DScene& S, int map, F3 uvw, F3 d0, F3 d1) {
+    const mi355pt_texmap& m = S.texmaps[map];
+    if (m.texture < 0) return f3(0, 0, 0);
+    const F3 pos = ld3(m.pos);
+    const F3 u = m3mul(m.itm, uvw - pos);
+    const F3 e0 = m3mul(m.itm, (d0 + uvw) - pos) - u;
+    const F3 e1 = m3mul(m.itm, (d1 + uvw) - pos) - u;
+    return tex_filtered(S, S.textures[m.texture], u, e0, e1);
+}
+PT_DEV F3 textured_color(const DScene& S, const float* color, int map, const Surf& h) {
+    const F3 c = ld3(color);
+    return map >= 0 ? c * texmap_sample(S, map, h.uvw, h.du0, h.du1) : c;
+}
+PT_DEV F3 textured_color_srgb(const DScene& S, const float* color, int map, const Surf& h) {
+    const F3 c = ld3(color);
+    if (map < 0) return c;
+    F3 mc = texmap_sample(S, map, h.uvw, h.du0, h.du1);
+    mc = f3(powf(mc.x, 2.2f), powf(mc.y, 2.2f), powf(mc.z, 2.2f));
+    return c * mc;
+}
+PT_DEV F3 sample_environment(const DScene& S, F3 dir) {
+    const F3 c = ld3(S.env_color);
+    if (S.env_map < 0) return c;
+    const F3 uvw = f3(0.5f - atan2f(dir.x, dir.y) / (2.0f * 3.14159274f), 0.5f + asinf(dir.z * 1.0f) / 3.14159274f, 0.0f);
+    const mi355pt_texmap& m = S.texmaps[S.env_map];
+    if (m.texture < 0) return c * f3(0, 0, 0);
+    return c * tex_point(S.textures[m.texture], m3mul(m.itm, uvw - ld3(m.pos)));
+}
+
+// ------------------------------------------------------------------ Disney (disneyBrdf.h)
+PT_DEV float dmin(float a, float b) { return a > b ? b : a; }
+PT_DEV float dmax(float a, float b) { return a < b ? b : a; }
+PT_DEV float dclamp(float t, float l, float r) { t = dmin(r, t); t = dmax(l, t); return t; }
+PT_DEV float mixf(float a, float b, float r) { return a * (1.0f - r) + b * r; }
+PT_DEV F3 mixv(F3 a, F3 b, float r) { return a * (1.0f - r) + b * r; }
+PT_DEV float gtr1(float NdotH, float a) {
+    if (a >= 1.0f) return kInvPI;
+    const float a2 = a * a;
+    const float t = 1.0f + (a2 - 1.0f) * NdotH * NdotH;
+    return (a2 - 1.0f) / (kPI * logf(a2) * t);
+}
+PT_DEV float gtr2(float NdotH, float a) {
+    const float a2 = a * a;
+    const float t = 1.0f + (a2 - 1.0f) * NdotH * NdotH;
+    return a2 / (kPI * t * t);
+}
+PT_DEV float smith_ggx(float NdotV, float a) {
+    const float a2 = a * a, b = NdotV * NdotV;
+    return 1.0f / (NdotV + sqrtf(a2 + b - a2 * b));
+}
+PT_DEV float schlick(float u) {
+    const float m = dclamp((float)(1.0 - (double)u), 0.0f, 1.0f);
+    const float m2 = m * m;
+    return m2 * m2 * m;
+}
+struct Disney {
+    F3 base;
+    float metallic, specular, roughness, specularTint, sheenTint, sheen, clearcoatGloss, clearcoat, subsurface, csw;
+};
+PT_DEV void disney_finish(Disney& s) {      // Clamp + InitCSW (disneyBrdf.h:108-131)
+    s.metallic = dclamp(s.metallic, 0.001f, 0.999f); s.specular = dclamp(s.specular, 0.001f, 0.999f);
+    s.roughness = dclamp(s.roughness, 0.001f, 0.999f); s.specularTint = dclamp(s.specularTint, 0.001f, 0.999f);
+    s.sheenTint = dclamp(s.sheenTint, 0.001f, 0.999f); s.sheen = dclamp(s.sheen, 0.001f, 0.999f);
+    s.clearcoatGloss = dclamp(s.clearcoatGloss, 0.001f, 0.999f); s.clearcoat = dclamp(s.clearcoat, 0.001f, 0.999f);
+    s.subsurface = dclamp(s.subsurface, 0.001f, 0.999f);
+    const F3 cd = s.base;
+    const float cd_lum = dot(cd, f3(0.3f, 0.6f, 0.1f));
+    const F3 c_tint = cd_lum > 0.0f ? (cd / cd_lum) : f3(1.0f, 1.0f, 1.0f);
+    const F3 c_spec0 = mixv((1.0f - s.specular * 0.3f) * mixv(f3(1, 1, 1), c_tint, s.specularTint), cd, s.metallic);
+    const float cs_lum = dot(c_spec0, f3(0.3f, 0.6f, 0.1f));
+    s.csw = cs_lum / (cs_lum + (1.0f - s.metallic) * cd_lum);
+}
+PT_DEV float disney_pdf(const Disney& s, float NdotH, float NdotL, float HdotL) {
+    const float d_pdf = NdotL * (1.0f / kPI);
+    const float r_pdf = gtr2(NdotH, dmax(0.001f, dmax(0.001f, s.roughness))) * NdotH / (4.0f * HdotL);
+    const float c_pdf = gtr1(NdotH, mixf(0.1f, 0.001f, mixf(0.1f, 0.001f, s.clearcoatGloss))) * NdotH / (4.0f * HdotL);
+    return c_pdf * s.clearcoat + (1.0f - s.clearcoat) * (s.csw * r_pdf + (1.0f - s.csw) * d_pdf);
+}
+PT_DEV F3 disney_eval(const Disney& s, float NdotL, float NdotV, float NdotH, float HdotL) {
+    if (NdotL <= 0.0f || NdotV <= 0.0f) return f3(0, 0, 0);
+    const F3 cd = s.base;
+    const float cd_lum = dot(cd, f3(0.3f, 0.6f, 0.1f));
+    const F3 c_tint = cd_lum > 0.0f ? (cd / cd_lum) : f3(1, 1, 1);
+    const F3 c_spec0 = mixv(s.specular * 0.3f * mixv(f3(1, 1, 1), c_tint, s.specularTint), cd, s.metallic);
+    const F3 c_sheen = mixv(f3(1, 1, 1), c_tint, s.sheenTint);
+    const float f_wo = schlick(NdotV), f_wi = schlick(NdotL);
+    const float fd90 = 0.5f + 2.0f * HdotL * HdotL * s.roughness;
+    const float fd = mixf(1.0f, fd90, f_wo) * mixf(1.0f, fd90, f_wi);
+    const float fss90 = HdotL * HdotL * s.roughness;
+    const float fss = mixf(1.0f, fss90, f_wo) * mixf(1.0f, fss90, f_wi);
+    const float ss = 1.25f * (fss * (1.0f / (NdotV + NdotL) - 0.5f) + 0.5f);
+    const float ro = dmax(0.001f, s.roughness);
+    const float ds = gtr2(NdotH, ro);
+    const float fh = schlick(HdotL);
+    const F3 fs = mixv(c_spec0, f3(1, 1, 1), fh);
+    const float r2 = s.roughness * 0.5f + 0.5f;
+    const float ro2 = r2 * r2;
+    float gs = smith_ggx(NdotV, ro2);
+    gs *= smith_ggx(NdotL, ro2);
+    const F3 f_sheen = fh * s.sheen * c_sheen;
+    const float dr = gtr1(NdotH, mixf(0.1f, 0.001f, s.clearcoatGloss));
+    const float fr = mixf(0.04f, 1.0f, fh);
+    const float gr = smith_ggx(NdotV, 0.25f) * smith_ggx(NdotL, 0.25f);
+    const F3 f = ((1.0f / kPI) * mixf(fd, ss, s.subsurface) * cd + f_sheen) * (1.0f - s.metallic) + gs * fs * ds + (0.25f * s.clearcoat) * gr * fr * dr;
+    return f * NdotL;
+}
+PT_DEV F3 reflect(F3 I, F3 N) { return I - 2.0f * dot(N, I) * N; }
+PT_DEV F3 disney_sample(const Disney& s, F3 V, F3 N, Rng& rng) {
+    float r1 = rng.U(), r2 = rng.U();
+    const F3 U = fabsf(N.z) < (1.0f - kFltEps) ? f3(0.0f, 0.0f, 1.0f) : f3(1.0f, 0.0f, 0.0f);
+    const F3 T = normalized(cross(U, N));
+    const F3 B = cross(N, T);
+    if (r1 < s.clearcoat) {
+        r1 /= s.clearcoat;
+        const float a = mixf(0.1f, 0.001f, s.clearcoatGloss);
+        const float cosTheta = sqrtf((1.0f - powf(a * a, 1.0f - r2)) / (1.0f - a * a));
+        const float sinTheta = sqrtf(dmax(0.0f, 1.0f - (cosTheta * cosTheta)));
+        const float phi = r1 * kTwoPI;
+        F3 H = normalized(f3(cosf(phi) * sinTheta, sinf(phi) * sinTheta, cosTheta));
+        H = H.x * T + H.y * B + H.z * N;
+        if (dot(H, V) <= 0.0f) H = H * -1.0f;
+        return reflect(neg(V), H);
+    }
+    r1 -= s.clearcoat;
+    r1 /= (1.0f - s.clearcoat);
+    if (r2 < s.csw) {
+        r2 /= s.csw;
+        const float a = dmax(0.001f, s.roughness);
+        const float cosTheta = sqrtf((1.0f - r2) / (1.0f + (a * a - 1.0f) * r2));
+        const float sinTheta = sqrtf(dmax(0.0f, 1.0f - (cosTheta * cosTheta)));
+        const float phi = r1 * kTwoPI;
+        F3 H = normalized(f3(cosf(phi) * sinTheta, sinf(phi) * sinTheta, cosTheta));
+        H = H.x * T + H.y * B + H.z * N;
+        if (dot(H, V) <= 0.0f) H = H * -1.0f;
+        return reflect(neg(V), H);
+    }
+    r2 -= s.csw;
+    r2 /= (1.0f - s.csw);
+    F3 d;
+    const float r = sqrtf(r1), phi = kTwoPI * r2;
+    d.x = r * cosf(phi); d.y = r * sinf(phi);
+    d.z = sqrtf(dmax(0.0f, 1.0f - d.x * d.x - d.y * d.y));
+    return T * d.x + B * d.y + N * d.z;
+}
+
+// ------------------------------------------------------------------ Cook-Torrance (brdf_cook_torrance.h, utils.cpp:12-19,110-151)
+PT_DEV void branchless_onb(F3 n, F3& b1, F3& b2) {
+    const float sign = copysignf(1.0f, n.z);
+    const float a = -1.0f / (sign + n.z);
+    const float b = n.x * n.y * a;
+    b1 = f3(1.0f + sign * n.x * n.x * a, sign * b, -sign * n.x);
+    b2 = f3(b, sign + n.y * n.y * a, -n.y);
+}
+PT_DEV F3 ggx_sample(float roughness, float& probability, Rng& rng) {
+    const float a = roughness * roughness;
+    const float F = rng.U() * 0.99999f;
+    const float theta = acosf(sqrtf((1.0f - F) / (F * (a * a - 1.0f) + 1.0f)));
+    float cosTheta = cosf(theta);
+    const float sinTheta = sinf(theta);
+    if (cosTheta < 0.0f) cosTheta = 0.0f;
+    const float beta = rng.U() * kTwoPI;
+    float bottom = (a * a - 1.0f) * cosTheta * cosTheta + 1.0f;
+    bottom = bottom * bottom;
+    if (bottom <= 0.0f) bottom = 0.001f;
+    probability = a * a * cosTheta * sinTheta * kInvPI / bottom;
+    if (probability <= 0.0f) probability = 0.001f;
+    return f3(sinTheta * cosf(beta), sinTheta * sinf(beta), cosTheta);
+}
+PT_DEV F3 cook_torrance(F3 L, F3 V, F3 N, F3 albedo, float roughness, float metalness) {
+    const F3 H = normalized(V + L);
+    F3 F0 = f3(0.04f, 0.04f, 0.04f);
+    F0 = f3(F0.x * (1.0f - metalness) + albedo.x * metalness, F0.y * (1.0f - metalness) + albedo.y * metalness,
+            F0.z * (1.0f - metalness) + albedo.z * metalness);
+    const float VDotH = cymax(dot(V, H), 0.0f);
+    const double q = (double)(1.0f - VDotH);
+    const float pw = (float)((q * q) * (q * q) * q);     // pow(float, 5.0) evaluated in double (:105)
+    const F3 F = F0 + neg(F0 - 1.0f) * pw;
+    const float a = roughness * roughness, a2 = a * a;
+    const float NdotH = cymax(dot(N, H), 0.0f);
+    float denom = cymax((NdotH * NdotH * (a2 - 1.0f) + 1.0f), 0.001f);
+    denom = kPI * denom * denom;
+    const float NDF = a2 / denom;
+    const float NdotV = cymax(dot(N, V), 0.0f), NdotL = cymax(dot(N, L), 0.0f);
+    const float k = roughness * roughness * 0.5f;
+    const float G = (NdotV / (NdotV * (1.0f - k) + k)) * (NdotL / (NdotL * (1.0f - k) + k));
+    const F3 numerator = NDF * G * F;
+    const float denominator = 4.0f * cymax(dot(N, V), 0.0f) * cymax(dot(N, L), 0.0f);
+    const F3 specular = numerator / cymax(denominator, 0.001f);
+    F3 kD = f3(1.0f, 1.0f, 1.0f) - F;
+    kD = kD * (1.0f - metalness);
+    return kD * albedo * kInvPI + specular;
+}
+
+// ------------------------------------------------------------------ material context
+// The reference re-evaluates textures and the shading frame inside Sample, ComputePdf and every
+// EvalBrdf call of a vertex (disneyMaterial.h:97-121 etc.); the values are deterministic, so they
+// are evaluated once per vertex here.
+struct MatCtx {
+    int kind;
+    Disney d;
+    F3 brdfN, Ngeo, albedo, emission;
+    float rough_raw, rough_eval, metal;
+};
+PT_DEV void mat_prepare(const DScene& S, const Surf& h, MatCtx& m) {
+    const mi355pt_material& mt = S.materials[h.mtl];
+    m.kind = mt.kind;
+    F3 N = h.N; N = N / len(N);
+    m.Ngeo = N;
+    m.brdfN = N;
+    if (mt.normal_map >= 0) {
+        const F3 c = texmap_sample(S, mt.normal_map, h.uvw, h.du0, h.du1);
+        const F3 tn = f3(2.0f * c.x - 1.0f, 2.0f * c.y - 1.0f, 2.0f * c.z - 1.0f);
+        F3 b = h.N * tn.z + normalized(h.B) * tn.y + normalized(h.T) * tn.x;
+        m.brdfN = b / len(b);
+    }
+    m.emission = f3(0, 0, 0);
+    if (mt.kind == MI355PT_MTL_DISNEY) {
+        m.d.base = textured_color_srgb(S, mt.albedo, mt.albedo_map, h);
+        m.d.roughness = textured_color(S, mt.roughness, mt.roughness_map, h).x;
+        m.d.metallic = textured_color(S, mt.metalness, mt.metalness_map, h).x;
+        m.d.clearcoat = mt.clearcoat; m.d.clearcoatGloss = mt.clearcoat_gloss; m.d.sheen = mt.sheen; m.d.sheenTint = mt.sheen_tint;
+        m.d.specular = mt.specular; m.d.specularTint = mt.specular_tint; m.d.subsurface = mt.subsurface;
+        disney_finish(m.d);
+        const int li = S.nodes[h.node].light;
+        if (li >= 0) m.emission = ld3(S.lights[li].intensity);      // disneyMaterial.h:193-198
+    } else {
+        m.albedo = textured_color_srgb(S, mt.albedo, mt.albedo_map, h);
+        m.rough_raw = textured_color(S, mt.roughness, mt.roughness_map, h).x;
+        m.rough_eval = m.rough_raw <= 0.0f ? 0.001f : m.rough_raw;
+        m.metal = textured_color(S, mt.metalness, mt.metalness_map, h).x;
+    }
+}
+PT_DEV float mat_pdf(const MatCtx& m, F3 wi, F3 wo) {
+    if (m.kind == MI355PT_MTL_DISNEY) {
+        const F3 H = normalized(wi + wo);
+        return disney_pdf(m.d, dot(m.brdfN, H), dot(m.brdfN, wi), dot(H, wi));
+    }
+    const float cosTheta = dot(wi, m.brdfN);
+    const float sinTheta = sqrtf(1.0f - cosTheta * cosTheta);
+    const float a = m.rough_raw * m.rough_raw;
+    float bottom = (a * a - 1.0f) * cosTheta * cosTheta + 1.0f;
+    bottom = bottom * bottom;
+    return a * a * cosTheta * sinTheta * kInvPI / bottom;
+}
+PT_DEV void mat_sample(const MatCtx& m, F3 wo, Rng& rng, F3& wi, float& pdf) {
+    if (m.kind == MI355PT_MTL_DISNEY) {
+        wi = disney_sample(m.d, wo, m.brdfN, rng);
+        pdf = mat_pdf(m, wi, wo);
+    } else {
+        F3 b1, b2;
+        branchless_onb(m.brdfN, b1, b2);
+        F3 sd = ggx_sample(m.rough_raw, pdf, rng);
+        sd = m.brdfN * sd.z + b1 * sd.x + b2 * sd.y;
+        wi = sd / len(sd);
+    }
+}
+PT_DEV F3 mat_eval(const MatCtx& m, F3 wi, F3 wo) {      // shadingNormal output == m.brdfN for both materials
+    if (m.kind == MI355PT_MTL_DISNEY) {
+        const F3 H = normalized(wi + wo);
+        return m.emission + disney_eval(m.d, dot(m.brdfN, wi), dot(m.brdfN, wo), dot(m.brdfN, H), dot(H, wi));
+    }
+    return cook_torrance(wi, wo, m.Ngeo, m.albedo, m.rough_eval, m.metal);
+}
+
+// ------------------------------------------------------------------ area light (lightcomponent.cpp, objects.cpp:474-503)
+PT_DEV void light_sample_point(const DScene& S, const DLight& L, Rng& rng, F3& sp, F3& sn) {
+    const DNodeXf& n = S.nodes[L.node];
+    const float x = rng.U() * 2.0f - 1.0f;
+    const float y = rng.U() * 2.0f - 1.0f;
+    sp = m4mulp(n.l2w, f3(x, y, 0.0f), 1.0f);
+    sn = normalized(m4mulp(n.l2w, f3(0.0f, 0.0f, 1.0f), 1.0f) - m4mulp(n.l2w, f3(0.0f, 0.0f, 0.0f), 1.0f));
+}
+PT_DEV float light_pdf(const DLight& L, F3 hitp, F3 sp, F3 sn, float distance) {
+    const float d2 = distance * distance;
+    const F3 nwi = normalized(hitp - sp);
+    const float c = cymax(dot(nwi, sn), 0.0001f);
+    return d2 / (L.area * c);
+}
+
+// LightVisTest (raytracer.cpp:67-152).  Returns true when BLOCKED; on "not blocked" lp/ln hold the
+// light hit point / normal in world space.
+template <bool COUNT>
+PT_DEV bool light_vis_test(const DScene& S, const Ray& wr, float tmax, const DLight& L, F3& lp, F3& ln, WorkCounters& wc) {
+    // (1) the light's own object, both sides
+    const DInst& li = S.insts[L.inst];
+    const Ray lr = to_inst(S, li, wr);
+    float lz; bool front; F3 P;
+    if (!plane_hit(lr.p, lr.d, SIDE_BOTH, lz, front, P)) return true;
+    {
+        Surf h; h.p = P; h.N = front ? f3(0.0f, 0.0f, 1.0f) : -1.0f * f3(0.0f, 0.0f, 1.0f);
+        h.T = f3(1.0f, 0.0f, 0.0f); h.B = f3(0.0f, 1.0f, 0.0f);
+        surf_to_world(S, li, h);
+        lp = h.p; ln = h.N;
+    }
+    if (!front) return true;
+    // (2) every other object: a front-face hit nearer than tmax and the light blocks
+    const float bound = tmax < lz ? tmax : lz;       // z < tmax && z < lightZ
+    for (int ii = 0; ii < S.num_insts; ii++) {
+        if (ii == L.inst) continue;
+        const DInst& in = S.insts[ii];
+        const Ray r = to_inst(S, in, wr);
+        if (in.kind == MI355PT_OBJ_PLANE) {
+            float t; bool f; F3 Q;
+            if (plane_hit(r.p, r.d, SIDE_FRONT, t, f, Q) && t < tmax && t < lz) return true;
+        } else if (in.kind == MI355PT_OBJ_MODEL) {
+            const DModel& mo = S.models[in.model];
+            const F3 inv = f3(1.0f, 1.0f, 1.0f) / r.d;
+            float tn;
+            if (!slab(mo.aabb, r.p, inv, tn)) continue;
+            for (int mi = 0; mi < mo.num_meshes; mi++) {
+                const DMesh& M = S.meshes[mo.first_mesh + mi];
+                if (!slab(M.aabb, r.p, inv, tn)) continue;
+                float b = bound; uint32_t dummy = 0;
+                if (traverse_mesh<true, COUNT>(S, M, r.p, r.d, inv, SIDE_FRONT, b, dummy, wc)) return true;
+            }
+        }
+    }
+    return false;
+}
+
+// ------------------------------------------------------------------ tone mapping (tonemapping.h:14-42)
+PT_DEV F3 aces(F3 v) {
+    const float mi[9] = {0.59719f, 0.07600f, 0.02840f, 0.35458f, 0.90834f, 0.13383f, 0.04823f, 0.01566f, 0.83777f};
+    const float mo[9] = {1.60475f, -0.10208f, -0.00327f, -0.53108f, 1.10813f, -0.07276f, -0.07367f, -0.00605f, 1.07602f};
+    v = m3mul(mi, v);
+    const F3 a = v * (v + 0.0245786f) - 0.000090537f;
+    const F3 b = v * (0.983729f * v + 0.4329510f) + 0.238081f;
+    v = a / b;
+    v = m3mul(mo, v);
+    v.x = v.x < 0.0f ? 0.0f : v.x; v.y = v.y < 0.0f ? 0.0f : v.y; v.z = v.z < 0.0f ? 0.0f : v.z;
+    v.x = v.x > 1.0f ? 1.0f : v.x; v.y = v.y > 1.0f ? 1.0f : v.y; v.z = v.z > 1.0f ? 1.0f : v.z;
+    return v;
+}
+
+}  // namespace ptd

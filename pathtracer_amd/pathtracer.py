@@ -1,0 +1,169 @@
+"""Host-side mirror of the reference's `PathTracer` interface over the C ABI.
+
+Reference: include/pathtracer.h:29-43 -- `Init(width, height)`, `Run()` (starts the
+workers, returns), `Join()` (blocks until the stop flag is seen), with the stop flag
+`outputing` polled once per sample (src/pathtracer.cpp:95-99) and the RGB8 image read by
+the GUI every 0.3 s (src/raytracer.cpp:449).  The same three calls are kept here; the
+workers are the HIP kernels behind libmi355pt.so.  There is no CPU fallback: every
+method raises if the HIP library is missing or no gfx950 device is present.
+"""
+import ctypes as C
+import threading
+
+import numpy as np
+
+from . import capi
+
+
+class DeviceScene:
+    """`LoadScene` result uploaded to one GPU (the scene globals of src/raytracer.cpp:33-43)."""
+
+    def __init__(self, scene, device=0):
+        self.lib = capi.load_library()
+        self.desc, self._keep = scene.to_desc()
+        self.device = device
+        h = C.c_void_p()
+        capi.check(self.lib, self.lib.mi355pt_scene_create(C.byref(self.desc), device, C.byref(h)), "mi355pt_scene_create")
+        self.h = h
+
+    def get_bvh(self, mesh=0):
+        nn, nf = capi.u32(0), capi.u32(0)
+        capi.check(self.lib, self.lib.mi355pt_scene_get_bvh(self.h, mesh, None, C.byref(nn), None, C.byref(nf)), "get_bvh")
+        nodes = (capi.BvhNode * max(1, nn.value))()
+        faces = np.zeros(max(1, nf.value), dtype=np.uint32)
+        capi.check(self.lib, self.lib.mi355pt_scene_get_bvh(self.h, mesh, nodes, C.byref(nn), faces.ctypes.data_as(C.POINTER(capi.u32)),
+                                                            C.byref(nf)), "get_bvh")
+        return nodes, faces[:nf.value], nn.value
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.mi355pt_scene_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class PathTracer:
+    """Drop-in for the reference's PathTracer (same method names and meaning)."""
+
+    def __init__(self, scene, device=0, seed=0x5EED, max_bounces=30, rr_start=3, sample_offset=0, sample_stride=1,
+                 spp_per_step=1):
+        self.dscene = scene if isinstance(scene, DeviceScene) else DeviceScene(scene, device)
+        self.lib = self.dscene.lib
+        self._cfg = dict(seed=seed, max_bounces=max_bounces, rr_start=rr_start, sample_offset=sample_offset,
+                         sample_stride=sample_stride, device=self.dscene.device)
+        self.spp_per_step = spp_per_step
+        self.h = None
+        self.outputing = threading.Event()      # the reference's global std::atomic<bool> outputing
+        self._thread = None
+        self.width = self.height = self.size = 0
+
+    # -- reference interface ------------------------------------------------------
+    def Init(self, width, height):
+        self.close_render()
+        self.width, self.height, self.size = int(width), int(height), int(width) * int(height)
+        self.params = capi.make_params(self.width, self.height, **self._cfg)
+        h = C.c_void_p()
+        capi.check(self.lib, self.lib.mi355pt_render_create(self.dscene.h, C.byref(self.params), C.byref(h)), "mi355pt_render_create")
+        self.h = h
+        self.outputing.clear()
+
+    def Run(self):
+        """Starts progressive rendering (non-blocking), like PathTracer::Run."""
+        def loop():
+            while not self.outputing.is_set():
+                self.step(self.spp_per_step)
+                self.sync()
+        self._thread = threading.Thread(target=loop, daemon=True)
+        self._thread.start()
+
+    def Join(self):
+        if self._thread is not None:
+            self._thread.join()
+            self._thread = None
+
+    def Pause(self):
+        """RayTracer::Pause (src/raytracer.cpp:455-459)."""
+        self.outputing.set()
+
+    # -- bounded variants used by tests / bench -------------------------------------
+    def step(self, spp=1):
+        capi.check(self.lib, self.lib.mi355pt_render_step(self.h, spp), "mi355pt_render_step")
+
+    def sync(self):
+        capi.check(self.lib, self.lib.mi355pt_render_sync(self.h), "mi355pt_render_sync")
+
+    def render(self, spp):
+        self.step(spp)
+        self.sync()
+        return self.GetPixels()
+
+    def GetPixels(self):
+        """renderImage.GetPixels(): (h, w, 3) uint8."""
+        out = np.zeros((self.height, self.width, 3), dtype=np.uint8)
+        capi.check(self.lib, self.lib.mi355pt_render_read_rgb8(self.h, out.ctypes.data), "read_rgb8")
+        return out
+
+    def read_accum(self):
+        mean = np.zeros((self.size, 3), dtype=np.float32)
+        cnt = np.zeros(self.size, dtype=np.uint32)
+        capi.check(self.lib, self.lib.mi355pt_render_read_accum(self.h, mean.ctypes.data, cnt.ctypes.data), "read_accum")
+        return mean, cnt
+
+    def write_accum(self, mean, cnt):
+        mean = np.ascontiguousarray(mean, dtype=np.float32)
+        cnt = np.ascontiguousarray(cnt, dtype=np.uint32)
+        capi.check(self.lib, self.lib.mi355pt_render_write_accum(self.h, mean.ctypes.data, cnt.ctypes.data), "write_accum")
+
+    def accum_device_ptrs(self):
+        a, b = C.c_void_p(), C.c_void_p()
+        capi.check(self.lib, self.lib.mi355pt_render_accum_device_ptrs(self.h, C.byref(a), C.byref(b)), "accum_device_ptrs")
+        return a.value, b.value
+
+    def trace_primary(self, x0=0, y0=0, x1=None, y1=None):
+        x1 = self.width if x1 is None else x1
+        y1 = self.height if y1 is None else y1
+        n = (x1 - x0) * (y1 - y0)
+        node, mesh, face = (np.zeros(n, dtype=np.int32) for _ in range(3))
+        t = np.zeros(n, dtype=np.float32)
+        capi.check(self.lib, self.lib.mi355pt_trace_primary(self.h, x0, y0, x1, y1, node.ctypes.data, mesh.ctypes.data,
+                                                            face.ctypes.data, t.ctypes.data), "trace_primary")
+        return node, mesh, face, t
+
+    def sample_radiance(self, pixel, sample):
+        pixel = np.ascontiguousarray(pixel, dtype=np.uint32)
+        sample = np.ascontiguousarray(sample, dtype=np.uint32)
+        lin = np.zeros((pixel.size, 3), dtype=np.float32)
+        mp = np.zeros((pixel.size, 3), dtype=np.float32)
+        capi.check(self.lib, self.lib.mi355pt_sample_radiance(self.h, pixel.ctypes.data, sample.ctypes.data, pixel.size,
+                                                              lin.ctypes.data, mp.ctypes.data), "sample_radiance")
+        return lin, mp
+
+    def set_profiling(self, events=True, count_work=False):
+        capi.check(self.lib, self.lib.mi355pt_render_set_profiling(self.h, int(events), int(count_work)), "set_profiling")
+
+    def stats(self):
+        st = capi.Stats()
+        capi.check(self.lib, self.lib.mi355pt_render_stats(self.h, C.byref(st)), "render_stats")
+        return {k: getattr(st, k) for k, _ in capi.Stats._fields_}
+
+    def reset_stats(self):
+        capi.check(self.lib, self.lib.mi355pt_render_reset_stats(self.h), "reset_stats")
+
+    def stream(self):
+        return self.lib.mi355pt_render_stream(self.h)
+
+    def close_render(self):
+        if getattr(self, "h", None):
+            self.lib.mi355pt_render_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close_render()
+        except Exception:
+            pass

@@ -1,0 +1,56 @@
+"""Shared helpers for the test-suite: small scenes and comparison metrics."""
+import os
+
+import numpy as np
+
+from pathtracer_amd import capi, scene, scenes
+
+ASSETS = scenes.ASSETS
+
+
+def small_scenes():
+    """name -> (scene builder, width, height): sizes the oracle finishes in seconds."""
+    def teapot_cornell(w, h):
+        s = scenes.cornell_c3(w, h, dof=0.0)
+        m = scene.MtlDisney("tp", albedo=(0.9, 0.9, 0.9), roughness=np.float32(0.3), metalness=np.float32(0.175), sheen=0.35,
+                            sheen_tint=0.78, specular=0.25, clearcoat=1.0)
+        s.materials.append(m)
+        tp = s.rootNode.AppendChild(scene.Node("teapot", scene.Model([scene.load_obj(os.path.join(ASSETS, "teapot.obj"))]), m))
+        tp.Scale(0.75); tp.Rotate((0, 0, 1), 30.0); tp.Translate((-4.5, 5, 7))
+        return s
+
+    def grid_small(w, h):
+        return scenes.grid_c4(12, 10, w, h)
+
+    def textured(w, h):
+        return scenes.textured_c2(w, h, tex_size=256)
+
+    return {
+        "cornell_c1": (lambda w, h: scenes.cornell_c1(w, h), 96, 96),
+        "cornell_c3_dof": (lambda w, h: scenes.cornell_c3(w, h, dof=0.5), 96, 64),
+        "teapot_cornell": (teapot_cornell, 96, 72),
+        "grid_small": (grid_small, 128, 72),
+        "textured_c2": (textured, 96, 54),
+    }
+
+
+def bvh_equal(nodes_a, faces_a, nodes_b, faces_b, n):
+    """Node-for-node comparison (bounds compared as floats: +0 == -0)."""
+    a = np.frombuffer(nodes_a, dtype=np.uint32)[:n * 10].reshape(n, 10)
+    b = np.frombuffer(nodes_b, dtype=np.uint32)[:n * 10].reshape(n, 10)
+    fa, fb = a[:, :6].copy().view(np.float32), b[:, :6].copy().view(np.float32)
+    return bool(np.array_equal(fa, fb)) and bool(np.array_equal(a[:, 6:], b[:, 6:])) and bool(np.array_equal(faces_a, faces_b))
+
+
+def radiance_agreement(a, b, rel=1e-3, floor=1e-3):
+    """Fraction of samples with max_c |a-b| <= rel * max(|b|, floor)  (north_star 1e-3)."""
+    err = np.abs(a - b).max(axis=1)
+    tol = rel * np.maximum(np.abs(b).max(axis=1), floor)
+    ok = err <= tol
+    return float(ok.mean()), ok
+
+
+def rel_mse(a, b):
+    """relMSE = mean (a-b)^2 / (b^2 + 1e-2)  (SURVEY 8d)."""
+    a = a.astype(np.float64); b = b.astype(np.float64)
+    return float(np.mean((a - b) ** 2 / (b ** 2 + 1e-2)))
