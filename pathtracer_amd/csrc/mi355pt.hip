@@ -286,7 +286,7 @@ __device__ __forceinline__ F3 finish_sample(F3 c, F3* linear) {
     if (isnan(s) || isinf(s)) c = f3(0, 0, 0);
     if (linear) *linear = c;
     const F3 m = aces(c);
-    return f3(powf(m.x, 0.4545f), powf(m.y, 0.4545f), powf(m.z, 0.4545f));
+    return f3(a_powf(m.x, 0.4545f), a_powf(m.y, 0.4545f), a_powf(m.z, 0.4545f));
 }
 __global__ void __launch_bounds__(kBlock) k_resolve(DPaths P, float* mean, uint32_t* cnt, uint8_t* rgb8, uint32_t pix_base,
                                                     uint32_t npix_chunk, uint32_t ns) {
@@ -610,6 +610,14 @@ int mi355pt_scene_create(const mi355pt_scene_desc* desc, int32_t device, mi355pt
     d.normals = sc->normals.p; d.uvw = sc->uvw.p; d.tangents = sc->tangents.p; d.bitangents = sc->bitangents.p;
     d.materials = sc->materials.p; d.texmaps = sc->texmaps.p; d.textures = sc->textures.p; d.lights = sc->lights.p; d.num_lights = (int)lights.size();
     memcpy(d.env_color, desc->env_color, sizeof(d.env_color)); d.env_map = desc->env_map;
+    for (int i = 0; i < 32; i++) {      // Texture::Sample tap offsets (scene.h:169-175), host libm like the reference
+        auto halton = [](int index, int base) { float r = 0; float f = 1.0f / (float)base; for (int k = index; k > 0; k /= base) { r += f * (k % base); f /= (float)base; } return r; };
+        float x = halton(i, 2), y = halton(i, 3);
+        const float rr = sqrtf(x) * 0.5f;
+        x = rr * sinf(y * (float)M_PI * 2);
+        y = rr * cosf(y * (float)M_PI * 2);
+        d.filter_taps[2 * i] = x; d.filter_taps[2 * i + 1] = y;
+    }
     *out = sc.release();
     return MI355PT_OK;
 }

@@ -22,6 +22,20 @@ constexpr float kBias = 0.0001f;
 constexpr float kFltEps = 1.1920928955078125e-7f;
 enum { SIDE_FRONT = 1, SIDE_BACK = 2, SIDE_BOTH = 3 };
 
+// ------------------------------------------------------------------ transcendental functions
+// The reference calls libm's float functions (sinf, cosf, powf, logf, acosf, ...).  glibc's are
+// correctly rounded in all but a vanishing fraction of arguments; ROCm's fp32 device functions are
+// 1-2 ulp.  Evaluating in fp64 and rounding once gives the correctly rounded fp32 result (up to
+// double-rounding cases ~1e-8), so device samples follow the same branches as the CPU reference.
+// These sit in shading code, far off the traversal critical path.
+PT_DEV float a_sinf(float x) { return (float)sin((double)x); }
+PT_DEV float a_cosf(float x) { return (float)cos((double)x); }
+PT_DEV float a_powf(float x, float y) { return (float)pow((double)x, (double)y); }
+PT_DEV float a_logf(float x) { return (float)log((double)x); }
+PT_DEV float a_acosf(float x) { return (float)acos((double)x); }
+PT_DEV float a_asinf(float x) { return (float)asin((double)x); }
+PT_DEV float a_atan2f(float y, float x) { return (float)atan2((double)y, (double)x); }
+
 // ------------------------------------------------------------------ vectors (cyVector.h semantics)
 struct F3 { float x, y, z; };
 struct F2 { float x, y; };
@@ -107,7 +121,7 @@ PT_DEV void camera_rays(const DCamera& c, uint32_t seed, uint32_t pixel, uint32_
     const float S = rng.U();
     const float r = sqrtf(S) * c.dof;
     const float theta = rng.U() * kTwoPI;
-    const float lx = r * cosf(theta), ly = r * sinf(theta);
+    const float lx = r * a_cosf(theta), ly = r * a_sinf(theta);
     const F3 right = ld3(c.right), up = ld3(c.up), front = ld3(c.front);
     const F3 lens = right * lx + up * ly;
     mainRay.p = ld3(c.pos) + right * lx + up * ly;

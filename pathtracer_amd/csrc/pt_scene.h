@@ -50,6 +50,7 @@ struct DScene {
     const DTexture* textures;
     const DLight*   lights;     int num_lights;
     float env_color[3];         int env_map;
+    float filter_taps[64];           // (x, y) of the 32 elliptic filter taps, scene.h:169-181
 };
 
 }  // namespace ptd

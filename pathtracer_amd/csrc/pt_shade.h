@@ -146,10 +146,9 @@ PT_DEV F3 tex_filtered(const DScene& S, const DTexture& t, F3 uvw, F3 d0, F3 d1)
     F3 c = tex_point(t, uvw);
     if (len2(d0) + len2(d1) == 0) return c;
     for (int i = 1; i < 32; i++) {
-        float x = halton(i, 2), y = halton(i, 3);
-        const float r = sqrtf(x) * 0.5f;
-        x = r * sinf(y * kPI * 2);
-        y = r * cosf(y * kPI * 2);
+        // elliptic tap offsets r*sin, r*cos of scene.h:170-175 are pixel-independent constants:
+        // tabulated on the host with libm (mi355pt.hip, init_filter_taps)
+        const float x = S.filter_taps[2 * i], y = S.filter_taps[2 * i + 1];
         c = c + tex_point(t, uvw + x * d0 + y * d1);
     }
     return c / 32.0f;
@@ -171,13 +170,13 @@ PT_DEV F3 textured_color_srgb(const DScene& S, const float* color, int map, cons
     const F3 c = ld3(color);
     if (map < 0) return c;
     F3 mc = texmap_sample(S, map, h.uvw, h.du0, h.du1);
-    mc = f3(powf(mc.x, 2.2f), powf(mc.y, 2.2f), powf(mc.z, 2.2f));
+    mc = f3(a_powf(mc.x, 2.2f), a_powf(mc.y, 2.2f), a_powf(mc.z, 2.2f));
     return c * mc;
 }
 PT_DEV F3 sample_environment(const DScene& S, F3 dir) {
     const F3 c = ld3(S.env_color);
     if (S.env_map < 0) return c;
-    const F3 uvw = f3(0.5f - atan2f(dir.x, dir.y) / (2.0f * 3.14159274f), 0.5f + asinf(dir.z * 1.0f) / 3.14159274f, 0.0f);
+    const F3 uvw = f3(0.5f - a_atan2f(dir.x, dir.y) / (2.0f * 3.14159274f), 0.5f + a_asinf(dir.z * 1.0f) / 3.14159274f, 0.0f);
     const mi355pt_texmap& m = S.texmaps[S.env_map];
     if (m.texture < 0) return c * f3(0, 0, 0);
     return c * tex_point(S.textures[m.texture], m3mul(m.itm, uvw - ld3(m.pos)));
@@ -193,7 +192,7 @@ PT_DEV float gtr1(float NdotH, float a) {
     if (a >= 1.0f) return kInvPI;
     const float a2 = a * a;
     const float t = 1.0f + (a2 - 1.0f) * NdotH * NdotH;
-    return (a2 - 1.0f) / (kPI * logf(a2) * t);
+    return (a2 - 1.0f) / (kPI * a_logf(a2) * t);
 }
 PT_DEV float gtr2(float NdotH, float a) {
     const float a2 = a * a;
@@ -269,10 +268,10 @@ PT_DEV F3 disney_sample(const Disney& s, F3 V, F3 N, Rng& rng) {
     if (r1 < s.clearcoat) {
         r1 /= s.clearcoat;
         const float a = mixf(0.1f, 0.001f, s.clearcoatGloss);
-        const float cosTheta = sqrtf((1.0f - powf(a * a, 1.0f - r2)) / (1.0f - a * a));
+        const float cosTheta = sqrtf((1.0f - a_powf(a * a, 1.0f - r2)) / (1.0f - a * a));
         const float sinTheta = sqrtf(dmax(0.0f, 1.0f - (cosTheta * cosTheta)));
         const float phi = r1 * kTwoPI;
-        F3 H = normalized(f3(cosf(phi) * sinTheta, sinf(phi) * sinTheta, cosTheta));
+        F3 H = normalized(f3(a_cosf(phi) * sinTheta, a_sinf(phi) * sinTheta, cosTheta));
         H = H.x * T + H.y * B + H.z * N;
         if (dot(H, V) <= 0.0f) H = H * -1.0f;
         return reflect(neg(V), H);
@@ -285,7 +284,7 @@ PT_DEV F3 disney_sample(const Disney& s, F3 V, F3 N, Rng& rng) {
         const float cosTheta = sqrtf((1.0f - r2) / (1.0f + (a * a - 1.0f) * r2));
         const float sinTheta = sqrtf(dmax(0.0f, 1.0f - (cosTheta * cosTheta)));
         const float phi = r1 * kTwoPI;
-        F3 H = normalized(f3(cosf(phi) * sinTheta, sinf(phi) * sinTheta, cosTheta));
+        F3 H = normalized(f3(a_cosf(phi) * sinTheta, a_sinf(phi) * sinTheta, cosTheta));
         H = H.x * T + H.y * B + H.z * N;
         if (dot(H, V) <= 0.0f) H = H * -1.0f;
         return reflect(neg(V), H);
@@ -294,7 +293,7 @@ PT_DEV F3 disney_sample(const Disney& s, F3 V, F3 N, Rng& rng) {
     r2 /= (1.0f - s.csw);
     F3 d;
     const float r = sqrtf(r1), phi = kTwoPI * r2;
-    d.x = r * cosf(phi); d.y = r * sinf(phi);
+    d.x = r * a_cosf(phi); d.y = r * a_sinf(phi);
     d.z = sqrtf(dmax(0.0f, 1.0f - d.x * d.x - d.y * d.y));
     return T * d.x + B * d.y + N * d.z;
 }
@@ -310,9 +309,9 @@ PT_DEV void branchless_onb(F3 n, F3& b1, F3& b2) {
 PT_DEV F3 ggx_sample(float roughness, float& probability, Rng& rng) {
     const float a = roughness * roughness;
     const float F = rng.U() * 0.99999f;
-    const float theta = acosf(sqrtf((1.0f - F) / (F * (a * a - 1.0f) + 1.0f)));
-    float cosTheta = cosf(theta);
-    const float sinTheta = sinf(theta);
+    const float theta = a_acosf(sqrtf((1.0f - F) / (F * (a * a - 1.0f) + 1.0f)));
+    float cosTheta = a_cosf(theta);
+    const float sinTheta = a_sinf(theta);
     if (cosTheta < 0.0f) cosTheta = 0.0f;
     const float beta = rng.U() * kTwoPI;
     float bottom = (a * a - 1.0f) * cosTheta * cosTheta + 1.0f;
@@ -320,7 +319,7 @@ PT_DEV F3 ggx_sample(float roughness, float& probability, Rng& rng) {
     if (bottom <= 0.0f) bottom = 0.001f;
     probability = a * a * cosTheta * sinTheta * kInvPI / bottom;
     if (probability <= 0.0f) probability = 0.001f;
-    return f3(sinTheta * cosf(beta), sinTheta * sinf(beta), cosTheta);
+    return f3(sinTheta * a_cosf(beta), sinTheta * a_sinf(beta), cosTheta);
 }
 PT_DEV F3 cook_torrance(F3 L, F3 V, F3 N, F3 albedo, float roughness, float metalness) {
     const F3 H = normalized(V + L);
