@@ -181,8 +181,10 @@ typedef struct mi355pt_stats {
     uint64_t closest_rays;      /* TraceNode calls                                     */
     uint64_t shadow_rays;       /* LightVisTest calls                                  */
     uint64_t samples;           /* RenderPixel calls                                   */
-    uint64_t bvh_node_visits;   /* internal-node records fetched (counting builds)     */
-    uint64_t bvh_tri_tests;     /* triangle records fetched (counting builds)          */
+    uint64_t bvh_node_visits;   /* closest-hit kernel: 64-B node records fetched (counting builds) */
+    uint64_t bvh_tri_tests;     /* closest-hit kernel: 48-B triangle records fetched   */
+    uint64_t shadow_node_visits;/* visibility kernel: ditto                             */
+    uint64_t shadow_tri_tests;
     double   extend_ms;         /* device time in the closest-hit kernel (HIP events)  */
     double   shade_ms;
     double   connect_ms;

@@ -84,7 +84,7 @@ class RenderParams(C.Structure):
 
 class Stats(C.Structure):
     _fields_ = [("closest_rays", u64), ("shadow_rays", u64), ("samples", u64), ("bvh_node_visits", u64),
-                ("bvh_tri_tests", u64), ("extend_ms", C.c_double), ("shade_ms", C.c_double),
+                ("bvh_tri_tests", u64), ("shadow_node_visits", u64), ("shadow_tri_tests", u64), ("extend_ms", C.c_double), ("shade_ms", C.c_double),
                 ("connect_ms", C.c_double), ("other_ms", C.c_double), ("extend_launches", u64)]
 
 

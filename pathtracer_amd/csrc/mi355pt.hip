@@ -44,7 +44,7 @@ struct DPaths {
     uint32_t *squeue;     // slots with shadow work this bounce
     uint32_t *counts;     // [b] = #paths entering bounce b (b >= 1)
     uint32_t *scounts;    // [b] = #paths with shadow work at bounce b
-    unsigned long long *stat;   // [0] closest rays [1] shadow rays [2] samples [3] node visits [4] tri tests
+    unsigned long long *stat;   // [0] closest rays [1] shadow rays [2] samples [3,4] extend node visits / tri tests [5,6] connect ditto
 };
 struct Params { uint32_t seed, width, height, max_bounces, rr_start; };
 
@@ -275,7 +275,7 @@ __global__ void __launch_bounds__(kBlock) k_connect(DScene S, DPaths P, uint32_t
 #undef PT_SH
     }
     wave_add64(rays, &P.stat[1]);
-    if (COUNT) { wave_add64(wc.nodes, &P.stat[3]); wave_add64(wc.tris, &P.stat[4]); }
+    if (COUNT) { wave_add64(wc.nodes, &P.stat[5]); wave_add64(wc.tris, &P.stat[6]); }
 }
 
 // ---------------------------------------------------------------------- resolve
@@ -872,6 +872,7 @@ int mi355pt_render_stats(mi355pt_render* r, mi355pt_stats* st) {
     unsigned long long h[8];
     HIP_TRY(hipMemcpy(h, r->P.stat, sizeof(h), hipMemcpyDeviceToHost));
     st->closest_rays = h[0]; st->shadow_rays = h[1]; st->samples = h[2]; st->bvh_node_visits = h[3]; st->bvh_tri_tests = h[4];
+    st->shadow_node_visits = h[5]; st->shadow_tri_tests = h[6];
     st->extend_ms = r->ms[0]; st->shade_ms = r->ms[1]; st->connect_ms = r->ms[2]; st->other_ms = r->ms[3];
     st->extend_launches = r->extend_launches;
     return MI355PT_OK;
