@@ -185,6 +185,7 @@ typedef struct mi355pt_stats {
     uint64_t bvh_tri_tests;     /* closest-hit kernel: 48-B triangle records fetched   */
     uint64_t shadow_node_visits;/* visibility kernel: ditto                             */
     uint64_t shadow_tri_tests;
+    uint64_t max_nodes_per_ray; /* closest-hit kernel: longest single traversal (counting builds) */
     double   extend_ms;         /* device time in the closest-hit kernel (HIP events)  */
     double   shade_ms;
     double   connect_ms;
@@ -258,6 +259,11 @@ int mi355pt_render_accum_device_ptrs(mi355pt_render* render, void** mean_rgb, vo
  *    floats) and the tone-mapped, gamma-corrected sample colour (3 floats).        */
 int mi355pt_trace_primary(mi355pt_render* render, uint32_t x0, uint32_t y0, uint32_t x1, uint32_t y1,
                           int32_t* node, int32_t* mesh, int32_t* face, float* t);
+/*  - trace_rays: TraceNode (src/raytracer.cpp:189-258, HIT_FRONT_AND_BACK) for `count` arbitrary
+ *    world-space rays (origins/dirs: 3 floats each, hasDiff = false), through the production
+ *    closest-hit kernel.  Same outputs as trace_primary.                               */
+int mi355pt_trace_rays(mi355pt_render* render, const float* origins, const float* dirs, uint32_t count,
+                       int32_t* node, int32_t* mesh, int32_t* face, float* t);
 int mi355pt_sample_radiance(mi355pt_render* render, const uint32_t* pixel, const uint32_t* sample,
                             uint32_t count, float* linear_rgb, float* mapped_rgb);
 

@@ -33,6 +33,7 @@ def lib():
         L.oracle_count_ordered_primary.argtypes = [vp, C.POINTER(capi.RenderParams)] + [capi.u32] * 4 + [C.c_void_p] * 2
         L.oracle_sample_radiance.argtypes = [vp, C.POINTER(capi.RenderParams), C.c_void_p, C.c_void_p, capi.u32, C.c_void_p, C.c_void_p]
         L.oracle_render.argtypes = [vp, C.POINTER(capi.RenderParams)] + [capi.u32] * 6 + [C.c_void_p] * 4
+        L.oracle_trace_rays.argtypes = [vp, C.c_void_p, C.c_void_p, capi.u32] + [C.c_void_p] * 4
         L.oracle_rng_u31.restype = capi.u32
         L.oracle_rng_u31.argtypes = [capi.u32] * 4
         L.oracle_halton.restype = C.c_float
@@ -75,6 +76,15 @@ class OracleScene:
         cnt = np.zeros(2, dtype=np.uint64)
         lib().oracle_trace_primary(self.h, C.byref(params), x0, y0, x1, y1, _p(node), _p(mesh), _p(face), _p(t), _p(cnt))
         return node, mesh, face, t, cnt
+
+    def trace_rays(self, origins, dirs):
+        origins = np.ascontiguousarray(origins, dtype=np.float32)
+        dirs = np.ascontiguousarray(dirs, dtype=np.float32)
+        n = origins.shape[0]
+        node, mesh, face = (np.zeros(n, dtype=np.int32) for _ in range(3))
+        t = np.zeros(n, dtype=np.float32)
+        lib().oracle_trace_rays(self.h, _p(origins), _p(dirs), n, _p(node), _p(mesh), _p(face), _p(t))
+        return node, mesh, face, t
 
     def count_ordered_primary(self, params, x0, y0, x1, y1):
         n = (x1 - x0) * (y1 - y0)

@@ -1405,6 +1405,20 @@ int oracle_trace_primary(const oracle_scene* o, const mi355pt_render_params* prm
     return 0;
 }
 
+// TraceNode for arbitrary world-space rays (hasDiff = false).
+int oracle_trace_rays(const oracle_scene* o, const float* origins, const float* dirs, uint32_t count,
+                      int32_t* node, int32_t* mesh, int32_t* face, float* t) {
+    const Scene& sc = o->sc;
+    for (uint32_t i = 0; i < count; i++) {
+        RayContext rc; rc.cameraRay.p = rd3(origins + 3 * i); rc.cameraRay.dir = rd3(dirs + 3 * i);
+        rc.rightRay = rc.cameraRay; rc.topRay = rc.cameraRay; rc.delta = 1.0f; rc.hasDiff = false;
+        HitInfo h;
+        bool hit = TraceNode(sc, h, rc, 0, HIT_FRONT_AND_BACK);
+        node[i] = hit ? h.node : -1; mesh[i] = hit ? h.mesh : -1; face[i] = hit ? h.face : -1; t[i] = h.z;
+    }
+    return 0;
+}
+
 // Ordered-traversal counters for the same primary rays (single-model scenes; SURVEY 8d n_node/n_tri).
 int oracle_count_ordered_primary(const oracle_scene* o, const mi355pt_render_params* prm, uint32_t x0, uint32_t y0, uint32_t x1, uint32_t y1,
                                  uint64_t* counters, int32_t* face_out) {

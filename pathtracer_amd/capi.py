@@ -84,7 +84,7 @@ class RenderParams(C.Structure):
 
 class Stats(C.Structure):
     _fields_ = [("closest_rays", u64), ("shadow_rays", u64), ("samples", u64), ("bvh_node_visits", u64),
-                ("bvh_tri_tests", u64), ("shadow_node_visits", u64), ("shadow_tri_tests", u64), ("extend_ms", C.c_double), ("shade_ms", C.c_double),
+                ("bvh_tri_tests", u64), ("shadow_node_visits", u64), ("shadow_tri_tests", u64), ("max_nodes_per_ray", u64), ("extend_ms", C.c_double), ("shade_ms", C.c_double),
                 ("connect_ms", C.c_double), ("other_ms", C.c_double), ("extend_launches", u64)]
 
 
@@ -98,7 +98,7 @@ SYMBOLS = [
     "mi355pt_scene_create", "mi355pt_scene_destroy", "mi355pt_scene_get_bvh", "mi355pt_build_bvh",
     "mi355pt_render_create", "mi355pt_render_destroy", "mi355pt_render_step", "mi355pt_render_sync",
     "mi355pt_render_read_rgb8", "mi355pt_render_read_accum", "mi355pt_render_write_accum",
-    "mi355pt_render_accum_device_ptrs", "mi355pt_trace_primary", "mi355pt_sample_radiance",
+    "mi355pt_render_accum_device_ptrs", "mi355pt_trace_primary", "mi355pt_trace_rays", "mi355pt_sample_radiance",
     "mi355pt_render_stats", "mi355pt_render_reset_stats", "mi355pt_render_set_profiling", "mi355pt_render_stream",
 ]
 
@@ -136,6 +136,7 @@ def load_library(path=None):
     lib.mi355pt_render_write_accum.argtypes = [vp, C.c_void_p, C.c_void_p]
     lib.mi355pt_render_accum_device_ptrs.argtypes = [vp, C.POINTER(vp), C.POINTER(vp)]
     lib.mi355pt_trace_primary.argtypes = [vp, u32, u32, u32, u32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.mi355pt_trace_rays.argtypes = [vp, C.c_void_p, C.c_void_p, u32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.mi355pt_sample_radiance.argtypes = [vp, C.c_void_p, C.c_void_p, u32, C.c_void_p, C.c_void_p]
     lib.mi355pt_render_stats.argtypes = [vp, C.POINTER(Stats)]
     lib.mi355pt_render_reset_stats.argtypes = [vp]

@@ -44,14 +44,16 @@ struct DPaths {
     uint32_t *squeue;     // slots with shadow work this bounce
     uint32_t *counts;     // [b] = #paths entering bounce b (b >= 1)
     uint32_t *scounts;    // [b] = #paths with shadow work at bounce b
+    unsigned long long *coop;  // per resident wave: kCoopCap entries of the shared stack used to finish long rays
+    uint32_t *work;       // [b] = next queue index to hand out in k_extend of bounce b (persistent refill)
     unsigned long long *stat;   // [0] closest rays [1] shadow rays [2] samples [3,4] extend node visits / tri tests [5,6] connect ditto
 };
-struct Params { uint32_t seed, width, height, max_bounces, rr_start; };
+struct Params { uint32_t seed, width, height, max_bounces, rr_start, long_ray; };
 
 #define PT_LD3(arr, cap, i) f3((arr)[(i)], (arr)[(size_t)(cap) + (i)], (arr)[2 * (size_t)(cap) + (i)])
 #define PT_ST3(arr, cap, i, v) do { (arr)[(i)] = (v).x; (arr)[(size_t)(cap) + (i)] = (v).y; (arr)[2 * (size_t)(cap) + (i)] = (v).z; } while (0)
 
-constexpr int kBlock = 256;
+constexpr int kBlock = kTravBlock;
 
 // wave64 compaction: one atomic per wave (ballot + mbcnt prefix)
 __device__ __forceinline__ void wave_enqueue(bool pred, uint32_t value, uint32_t* queue, uint32_t* counter) {
@@ -96,23 +98,234 @@ __global__ void __launch_bounds__(kBlock) k_init(DPaths P, Params prm, uint32_t 
 }
 
 // ---------------------------------------------------------------------- extend (closest hit)
+// TraceNode -> Model::IntersectRay -> TraceBVHNode -> IntersectRayWithFace for every queued ray.
+// Persistent waves with per-lane ray refill: path lengths through the BVH are heavy-tailed (a
+// grazing ray crosses hundreds of nodes, its neighbours a dozen), so a lane that finishes its ray
+// pulls the next one from a global counter instead of idling until the slowest lane of its wave
+// is done.  Each lane runs a small state machine (fetch -> next object -> next mesh -> traverse);
+// within a wave, node steps and the (expensive, bit-exact) triangle tests are run in separate
+// phases so that each executes with as many lanes active as possible.
+enum { ST_FETCH = 0, ST_INST, ST_MESH, ST_TRAV, ST_DONE };
+constexpr int kNodeSteps = 4;
+// A ray that has taken more than kLongRay node steps in one mesh is finished by its whole wave:
+// the 64 lanes pop 64 entries of a shared (per-wave, global-memory) stack at a time.  This bounds the
+// kernel's tail -- the longest single traversal (thousands of dependent node fetches for a ray that
+// skims the whole grid) would otherwise set the kernel time.  The result is unchanged: it is the
+// minimum over the same triangle set in (t, slot) order, whatever order the entries are visited in.
+constexpr uint32_t kLongRayDefault = 128;     // override: MI355PT_LONG_RAY (0 = every traversal is finished cooperatively)
+constexpr uint32_t kCoopCap = 4096;          // entries of the shared stack per wave
+constexpr uint32_t kCoopStride = kCoopCap + 64;   // slack: the overflow guard may overshoot by a few pushes
+__device__ __forceinline__ unsigned long long coop_load(const unsigned long long* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // sc1: served by L2, never a stale L1 line
+}
+__device__ __forceinline__ void coop_store(unsigned long long* p, unsigned long long v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ unsigned long long coop_entry(uint32_t ref, float tnear) { return ((unsigned long long)__float_as_uint(tnear) << 32) | ref; }
+__device__ __forceinline__ F3 shfl3(F3 v, int j) { return f3(__shfl(v.x, j), __shfl(v.y, j), __shfl(v.z, j)); }
+
 template <bool COUNT>
-__global__ void __launch_bounds__(kBlock) k_extend(DScene S, DCamera cam, DPaths P, Params prm, uint32_t bounce, uint32_t n0) {
+__global__ void __launch_bounds__(kBlock) k_extend(DScene S, DCamera cam, DPaths P, Params prm, uint32_t bounce, uint32_t n0, uint32_t jitter) {
     const uint32_t n = bounce == 0 ? n0 : P.counts[bounce];
     const uint32_t* q = bounce == 0 ? nullptr : P.queue[bounce & 1];
+    uint32_t* work = &P.work[bounce];
+    const size_t cap = P.cap;
     WorkCounters wc; wc.nodes = 0; wc.tris = 0;
-    const uint32_t nb = gridDim.x;
-    for (uint32_t base = xcd_block(blockIdx.x, nb) * kBlock; base < n; base += nb * kBlock) {
-        const uint32_t i = base + threadIdx.x;
-        if (i >= n) continue;
-        const uint32_t slot = q ? q[i] : i;
-        Ray r;
-        if (bounce == 0) { F3 rd, td; camera_rays(cam, prm.seed, P.pix[slot], P.smp[slot], prm.width, true, r, rd, td); }
-        else { r.p = f3(P.ray[slot], P.ray[(size_t)P.cap + slot], P.ray[2 * (size_t)P.cap + slot]);
-               r.d = f3(P.ray[3 * (size_t)P.cap + slot], P.ray[4 * (size_t)P.cap + slot], P.ray[5 * (size_t)P.cap + slot]); }
-        const HitRec h = trace_closest<COUNT>(S, r, wc);
-        P.ht[slot] = h.t; P.hinst[slot] = h.inst; P.hmesh[slot] = h.mesh; P.hslot[slot] = h.slot;
+    extern __shared__ uint32_t sm_stack[];       // stack_entries x kBlock dwords, sized by the host from the tree depth
+#define PT_STK(i) sm_stack[(i) * kBlock + threadIdx.x]
+    float stack_t[kStackSize];
+    const int lane = __lane_id();
+    int state = ST_FETCH, ii = 0, mi = 0, sp = 0;
+    uint32_t slot = 0, lf = 0, lc = 0, bslot = 0;
+    float bt = 0.0f, pabs = 0.0f;
+    bool changed = false;
+    Ray wr, lr; wr.p = wr.d = lr.p = lr.d = f3(0, 0, 0);
+    F3 inv = f3(0, 0, 0);
+    HitRec best; best.t = kBig; best.inst = -1; best.mesh = -1; best.slot = 0;
+    uint32_t ray_nodes = 0, steps = 0;
+    unsigned long long* coop = P.coop + (size_t)(blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6)) * kCoopStride;
+    for (;;) {
+        // ---- refill idle lanes
+        const unsigned long long need = __ballot(state == ST_FETCH);
+        if (need) {
+            const int leader = __ffsll((long long)need) - 1;
+            uint32_t base = 0;
+            if (lane == leader) base = atomicAdd(work, (uint32_t)__popcll(need));
+            base = __shfl(base, leader);
+            if (state == ST_FETCH) {
+                const uint32_t idx = base + (uint32_t)__popcll(need & ((1ull << lane) - 1ull));
+                if (idx < n) {
+                    slot = q ? q[idx] : idx;
+                    if (bounce == 0 && jitter != 2) { F3 rd, td; camera_rays(cam, prm.seed, P.pix[slot], P.smp[slot], prm.width, jitter != 0, wr, rd, td); }
+                    else { wr.p = f3(P.ray[slot], P.ray[cap + slot], P.ray[2 * cap + slot]);
+                           wr.d = f3(P.ray[3 * cap + slot], P.ray[4 * cap + slot], P.ray[5 * cap + slot]); }
+                    best.t = kBig; best.inst = -1; best.mesh = -1; best.slot = 0;
+                    ii = 0; state = ST_INST;
+                    if (COUNT) ray_nodes = 0;
+                } else state = ST_DONE;
+            }
+        }
+        if (__ballot(state != ST_DONE) == 0) break;
+        // ---- next object of the scene graph (TraceNode, raytracer.cpp:189-258: earlier object wins ties)
+        if (state == ST_INST) {
+            if (ii >= S.num_insts) {
+                P.ht[slot] = best.t; P.hinst[slot] = best.inst; P.hmesh[slot] = best.mesh; P.hslot[slot] = best.slot;
+                state = ST_FETCH;
+                if (COUNT) atomicMax(&P.stat[7], (unsigned long long)ray_nodes);
+            } else {
+                const DInst& in = S.insts[ii];
+                lr = to_inst(S, in, wr);
+                if (in.kind == MI355PT_OBJ_PLANE) {
+                    float t; bool front; F3 Pp;
+                    if (plane_hit(lr.p, lr.d, SIDE_BOTH, t, front, Pp) && t < best.t) { best.t = t; best.inst = ii; best.mesh = -1; best.slot = 0; }
+                    ii++;
+                } else if (in.kind == MI355PT_OBJ_MODEL) {
+                    inv = f3(1.0f, 1.0f, 1.0f) / lr.d;
+                    pabs = prune_abs(lr.p);
+                    float tn;
+                    if (!slab(S.models[in.model].aabb, lr.p, inv, tn)) ii++;       // Model::IntersectRay, model.cpp:212
+                    else { mi = 0; state = ST_MESH; }
+                } else ii++;
+            }
+        }
+        // ---- next mesh of the model (model.cpp:223-245)
+        if (state == ST_MESH) {
+            const DModel& mo = S.models[S.insts[ii].model];
+            if (mi >= mo.num_meshes) { ii++; state = ST_INST; }
+            else {
+                const DMesh& M = S.meshes[mo.first_mesh + mi];
+                float tn;
+                if (!slab(M.aabb, lr.p, inv, tn)) mi++;
+                else {
+                    // start from the global best with bslot = 0: an equal-t candidate of a later mesh / object loses
+                    bt = best.t; bslot = 0; changed = false; sp = 0; lc = 0; steps = 0;
+                    if (M.root_cnt == 0xFFFFFFFFu) {
+                        if (COUNT) wc.nodes++;
+                        if (!slab(M.root_bound, lr.p, inv, tn)) mi++;
+                        else { PT_STK(0) = M.root_ref; stack_t[0] = -kBig; sp = 1; state = ST_TRAV; }
+                    } else {
+                        uint32_t first = M.root_ref, cnt = M.root_cnt;
+                        while (cnt) { const uint32_t c = cnt > 15u ? 15u : cnt; if (sp < kStackSize) { PT_STK(sp) = kLeafFlag | (c << 27) | first; sp++; } first += c; cnt -= c; }
+                        state = ST_TRAV;
+                    }
+                }
+            }
+        }
+        // ---- cooperative finish of long rays (see kLongRay)
+        unsigned long long longmask = __ballot(state == ST_TRAV && steps >= prm.long_ray);
+        while (longmask) {
+            const int j = __ffsll((long long)longmask) - 1;
+            longmask &= longmask - 1;
+            const F3 co = shfl3(lr.p, j), cd = shfl3(lr.d, j), cinv = shfl3(inv, j);
+            const float cpabs = prune_abs(co);
+            float gbt = __shfl(bt, j); uint32_t gslot = __shfl(bslot, j);
+            bool gchanged = false;
+            uint32_t sc = 0;
+            if (lane == j) {                                  // lane j hands its private stack (and pending leaf) over
+                for (int k = 0; k < sp; k++) coop_store(&coop[k], coop_entry(PT_STK(k), stack_t[k]));
+                sc = (uint32_t)sp;
+                if (lc > 0) { coop_store(&coop[sc], coop_entry(kLeafFlag | (lc << 27) | lf, -kBig)); sc++; }
+                sp = 0; lc = 0; steps = 0;
+            }
+            sc = __shfl(sc, j);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            while (sc > 0) {
+                uint32_t m = sc < 64u ? sc : 64u;
+                if (kCoopCap - sc < 4u * 64u) { const uint32_t room = (kCoopCap - sc) / 4u; m = room < m ? (room ? room : 1u) : m; }
+                const bool has = (uint32_t)lane < m;
+                unsigned long long e = 0;
+                if (has) e = coop_load(&coop[sc - 1 - (uint32_t)lane]);
+                sc -= m;
+                float mbt = gbt; uint32_t mslot = gslot;
+                unsigned long long pv[4]; int np = 0;
+                if (has) {
+                    const uint32_t ref = (uint32_t)e; const float tn = __uint_as_float((uint32_t)(e >> 32));
+                    if (ref & kLeafFlag) {
+                        const uint32_t first = ref & kLeafSlotMask, cnt = (ref >> 27) & 15u;
+                        for (uint32_t k = 0; k < cnt; k++) { const Tri T = load_tri(S.tris, first + k); if (COUNT) wc.tris++; tri_closest(T, co, cd, SIDE_BOTH, first + k, mbt, mslot); }
+                    } else if (!beyond(tn, mbt, cpabs)) {
+                        const float4* np4 = S.bvh_nodes + 4 * (size_t)ref;
+                        const float4 w0 = np4[0], w1 = np4[1], w2 = np4[2], w3 = np4[3];
+                        if (COUNT) { wc.nodes++; }
+                        const float lb[6] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y};
+                        const float rb[6] = {w1.z, w1.w, w2.x, w2.y, w2.z, w2.w};
+                        const uint32_t cref[2] = {__float_as_uint(w3.x), __float_as_uint(w3.y)}, ccnt[2] = {__float_as_uint(w3.z), __float_as_uint(w3.w)};
+                        for (int c = 0; c < 2; c++) {
+                            if (ccnt[c] == 0xFFFFFFFFu) { float tc; if (slab(c ? rb : lb, co, cinv, tc) && !beyond(tc, mbt, cpabs)) pv[np++] = coop_entry(cref[c], tc); }
+                            else if (ccnt[c] <= 15u) { if (ccnt[c]) pv[np++] = coop_entry(kLeafFlag | (ccnt[c] << 27) | cref[c], -kBig); }
+                            else for (uint32_t k = 0; k < ccnt[c]; k++) { const Tri T = load_tri(S.tris, cref[c] + k); if (COUNT) wc.tris++; tri_closest(T, co, cd, SIDE_BOTH, cref[c] + k, mbt, mslot); }
+                        }
+                    }
+                }
+                // wave minimum in (t, slot) order.  Accepted distances are >= 0 or -0.0 (the reference's `t < 0`
+                // rejects neither zero, and compares them equal): order by the float bits with both zeros mapped
+                // to one key, then take the winner's actual value so that a -0.0 is reported as the reference would.
+                const unsigned long long lkey = ((unsigned long long)(mbt == 0.0f ? 0u : __float_as_uint(mbt)) << 32) | mslot;
+                unsigned long long key = lkey;
+                for (int o = 32; o > 0; o >>= 1) { const unsigned long long other = __shfl_xor(key, o); key = other < key ? other : key; }
+                const unsigned long long prev = ((unsigned long long)(gbt == 0.0f ? 0u : __float_as_uint(gbt)) << 32) | gslot;
+                if (key != prev) {
+                    const int winner = __ffsll((long long)__ballot(lkey == key)) - 1;
+                    gbt = __shfl(mbt, winner); gslot = __shfl(mslot, winner); gchanged = true;
+                }
+                for (int k = 0; k < 4; k++) {
+                    const unsigned long long pm = __ballot(np > k);
+                    if (np > k) coop_store(&coop[sc + (uint32_t)__popcll(pm & ((1ull << lane) - 1ull))], pv[k]);
+                    sc += (uint32_t)__popcll(pm);
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            if (lane == j && gchanged) { bt = gbt; bslot = gslot; changed = true; }
+        }
+        // ---- node phase: lanes without a pending leaf pop / visit up to kNodeSteps entries
+        for (int it = 0; it < kNodeSteps; it++) {
+            const bool want = state == ST_TRAV && lc == 0;
+            if (__ballot(want) == 0) break;
+            if (!want) continue;
+            if (sp == 0) {                                  // this mesh is finished
+                if (changed) { best.t = bt; best.inst = ii; best.mesh = mi; best.slot = bslot; }
+                mi++; state = ST_MESH;
+                continue;
+            }
+            sp--;
+            const uint32_t e = PT_STK(sp);
+            if (e & kLeafFlag) { lf = e & kLeafSlotMask; lc = (e >> 27) & 15u; continue; }
+            const float4* np = S.bvh_nodes + 4 * (size_t)e;
+            const float4 w0 = np[0], w1 = np[1], w2 = np[2], w3 = np[3];
+            if (beyond(stack_t[sp], bt, pabs)) continue;    // pruned by a hit found since the push
+            if (COUNT) { wc.nodes++; ray_nodes++; }
+            steps++;
+            const float lb[6] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y};
+            const float rb[6] = {w1.z, w1.w, w2.x, w2.y, w2.z, w2.w};
+            const uint32_t lref = __float_as_uint(w3.x), rref = __float_as_uint(w3.y), lcnt = __float_as_uint(w3.z), rcnt = __float_as_uint(w3.w);
+            float tl = -kBig, tr = -kBig;
+            bool hl = false, hr = false;
+            if (lcnt == 0xFFFFFFFFu) { hl = slab(lb, lr.p, inv, tl); if (beyond(tl, bt, pabs)) hl = false; }
+            if (rcnt == 0xFFFFFFFFu) { hr = slab(rb, lr.p, inv, tr); if (beyond(tr, bt, pabs)) hr = false; }
+            const bool left_first = !(tr < tl);
+            if (hl && hr) {
+                if (sp + 2 <= kStackSize) {
+                    if (left_first) { PT_STK(sp) = rref; stack_t[sp] = tr; sp++; PT_STK(sp) = lref; stack_t[sp] = tl; sp++; }
+                    else { PT_STK(sp) = lref; stack_t[sp] = tl; sp++; PT_STK(sp) = rref; stack_t[sp] = tr; sp++; }
+                }
+            } else if (hl) { if (sp < kStackSize) { PT_STK(sp) = lref; stack_t[sp] = tl; sp++; } }
+            else if (hr) { if (sp < kStackSize) { PT_STK(sp) = rref; stack_t[sp] = tr; sp++; } }
+            // leaf children go on top: popped first (cheap, and they shrink the pruning distance early).
+            // The reference never tests a leaf's bound (model.cpp:6-25), so neither do we.
+            if (lcnt != 0xFFFFFFFFu) { uint32_t first = lref, cnt = lcnt; while (cnt) { const uint32_t c = cnt > 15u ? 15u : cnt; if (sp < kStackSize) { PT_STK(sp) = kLeafFlag | (c << 27) | first; sp++; } first += c; cnt -= c; } }
+            if (rcnt != 0xFFFFFFFFu) { uint32_t first = rref, cnt = rcnt; while (cnt) { const uint32_t c = cnt > 15u ? 15u : cnt; if (sp < kStackSize) { PT_STK(sp) = kLeafFlag | (c << 27) | first; sp++; } first += c; cnt -= c; } }
+        }
+        // ---- triangle phase: every lane holding a leaf tests its triangles
+        while (__ballot(state == ST_TRAV && lc > 0) != 0) {
+            if (state == ST_TRAV && lc > 0) {
+                const Tri T = load_tri(S.tris, lf);
+                if (COUNT) wc.tris++;
+                changed |= tri_closest(T, lr.p, lr.d, SIDE_BOTH, lf, bt, bslot);
+                lf++; lc--;
+            }
+        }
     }
+#undef PT_STK
     if (COUNT) { wave_add64(wc.nodes, &P.stat[3]); wave_add64(wc.tris, &P.stat[4]); }
 }
 
@@ -239,6 +452,8 @@ __global__ void __launch_bounds__(kBlock) k_connect(DScene S, DPaths P, uint32_t
     const uint32_t n = P.scounts[bounce];
     const size_t cap = P.cap;
     WorkCounters wc; wc.nodes = 0; wc.tris = 0;
+    __shared__ uint32_t sm_stack[kStackSize * kBlock];
+    uint32_t* lds = sm_stack + threadIdx.x;
     unsigned long long rays = 0;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const uint32_t slot = P.squeue[i];
@@ -252,13 +467,13 @@ __global__ void __launch_bounds__(kBlock) k_connect(DScene S, DPaths P, uint32_t
         if (flags & 1u) {
             r.d = f3(PT_SH(SH_W1X), PT_SH(SH_W1Y), PT_SH(SH_W1Z));
             rays++;
-            if (!light_vis_test<COUNT>(S, r, PT_SH(SH_TMAX1), L, lp, ln, wc))
+            if (!light_vis_test<COUNT>(S, r, PT_SH(SH_TMAX1), L, lp, ln, wc, lds))
                 direct = direct + f3(PT_SH(SH_C1X), PT_SH(SH_C1Y), PT_SH(SH_C1Z));
         }
         if (flags & 2u) {
             r.d = f3(PT_SH(SH_W2X), PT_SH(SH_W2Y), PT_SH(SH_W2Z));
             rays++;
-            if (!light_vis_test<COUNT>(S, r, kBig, L, lp, ln, wc)) {
+            if (!light_vis_test<COUNT>(S, r, kBig, L, lp, ln, wc, lds)) {
                 const F3 hp = f3(PT_SH(SH_HPX), PT_SH(SH_HPY), PT_SH(SH_HPZ));
                 const float lightPdf = light_pdf(L, hp, lp, ln, len(lp - hp));
                 if (!(lightPdf <= 0.0f)) {
@@ -324,17 +539,17 @@ __global__ void k_stats(DPaths P, uint32_t n0, uint32_t max_bounces) {
 }
 
 // ---------------------------------------------------------------------- primary-hit parity hook
-template <bool COUNT>
-__global__ void __launch_bounds__(kBlock) k_primary(DScene S, DCamera cam, Params prm, uint32_t x0, uint32_t y0, uint32_t rw, uint32_t rh,
-                                                    int32_t* node, int32_t* mesh, int32_t* face, float* t, unsigned long long* stat) {
-    WorkCounters wc; wc.nodes = 0; wc.tris = 0;
+// Runs the production k_extend on GenCameraRayContext(x, y, 0, 0) rays (jitter off) and decodes the hit records.
+__global__ void __launch_bounds__(kBlock) k_primary_init(DPaths P, Params prm, uint32_t x0, uint32_t y0, uint32_t rw, uint32_t rh) {
     const uint32_t n = rw * rh;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const uint32_t ly = i / rw, lx = i - ly * rw;
-        const uint32_t pixel = (y0 + ly) * prm.width + (x0 + lx);
-        Ray r; F3 rd, td;
-        camera_rays(cam, prm.seed, pixel, 0, prm.width, false, r, rd, td);
-        const HitRec h = trace_closest<COUNT>(S, r, wc);
+        P.pix[i] = (y0 + ly) * prm.width + (x0 + lx); P.smp[i] = 0;
+    }
+}
+__global__ void __launch_bounds__(kBlock) k_primary_out(DScene S, DPaths P, uint32_t n, int32_t* node, int32_t* mesh, int32_t* face, float* t) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        HitRec h; h.t = P.ht[i]; h.inst = P.hinst[i]; h.mesh = P.hmesh[i]; h.slot = P.hslot[i];
         t[i] = h.t;
         if (h.inst < 0) { node[i] = -1; mesh[i] = -1; face[i] = -1; }
         else {
@@ -347,7 +562,6 @@ __global__ void __launch_bounds__(kBlock) k_primary(DScene S, DCamera cam, Param
             }
         }
     }
-    if (COUNT) { wave_add64(wc.nodes, &stat[3]); wave_add64(wc.tris, &stat[4]); }
 }
 
 // ====================================================================== host side
@@ -409,7 +623,7 @@ struct mi355pt_render {
     struct Ev { hipEvent_t a, b; int kind; };
     std::vector<Ev> events;
     double ms[4] = {0, 0, 0, 0}; uint64_t extend_launches = 0;
-    int grid = 2048;
+    int grid = 2048, extend_grid = 768; size_t extend_lds = 0; uint32_t long_ray = kLongRayDefault;
     ~mi355pt_render() {
         for (auto& e : events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
         for (void* p : allocs) (void)hipFree(p);
@@ -531,14 +745,14 @@ int mi355pt_scene_create(const mi355pt_scene_desc* desc, int32_t device, mi355pt
         } else {
             ptb::build_tree(s.vertices, s.faces, s.num_faces, s.aabb, threads, tree);
         }
-        if (tree.max_depth + 2 > kStackSize) return fail(MI355PT_ERR_TOO_LARGE, "BVH deeper than the traversal stack");
+        if (tree.max_depth + 4 > kStackSize) return fail(MI355PT_ERR_TOO_LARGE, "BVH deeper than the traversal stack");
         sc->max_depth = std::max(sc->max_depth, tree.max_depth);
         ptb::FlatMesh flat;
         ptb::flatten_tree(tree, flat);
         DMesh& d = meshes[mi];
         memcpy(d.aabb, s.aabb, sizeof(d.aabb)); memcpy(d.root_bound, tree.nodes[0].bound, sizeof(d.root_bound));
         const uint32_t node_base = (uint32_t)(bvh_nodes.size() / 4), tri_base = (uint32_t)(tris.size() / 3);
-        if ((uint64_t)tri_base + flat.slot_face.size() > 0xFFFFFFF0ull) return fail(MI355PT_ERR_TOO_LARGE, "more than 2^32 triangles");
+        if ((uint64_t)tri_base + flat.slot_face.size() > (uint64_t)kLeafSlotMask) return fail(MI355PT_ERR_TOO_LARGE, "more than 2^27 triangles");
         d.face_base = (uint32_t)(faces.size() / 4); d.vert_base = (uint32_t)(normals.size() / 3);
         d.has_tangents = (s.tangents && s.bitangents) ? 1 : 0; d.pad = 0;
         const bool root_internal = flat.root_cnt == ptb::kInternal;
@@ -676,14 +890,26 @@ int mi355pt_render_create(mi355pt_scene* scene, const mi355pt_render_params* par
     HIP_TRY(dalloc((void**)&P.sh, cap * 4 * kShFields));
     HIP_TRY(dalloc((void**)&P.queue[0], cap * 4)); HIP_TRY(dalloc((void**)&P.queue[1], cap * 4)); HIP_TRY(dalloc((void**)&P.squeue, cap * 4));
     const size_t nb = params->max_bounces + 2;
-    HIP_TRY(dalloc((void**)&P.counts, nb * 4)); HIP_TRY(dalloc((void**)&P.scounts, nb * 4));
+    HIP_TRY(dalloc((void**)&P.counts, nb * 4)); HIP_TRY(dalloc((void**)&P.scounts, nb * 4)); HIP_TRY(dalloc((void**)&P.work, nb * 4));
     HIP_TRY(dalloc((void**)&P.stat, 8 * sizeof(unsigned long long)));
-    HIP_TRY(hipMemset(P.stat, 0, 8 * sizeof(unsigned long long)));
+    HIP_TRY(hipMemsetAsync(P.stat, 0, 8 * sizeof(unsigned long long), r->stream));
     HIP_TRY(dalloc((void**)&r->mean, npix * 12)); HIP_TRY(dalloc((void**)&r->cnt, npix * 4)); HIP_TRY(dalloc((void**)&r->rgb8, npix * 3));
-    HIP_TRY(hipMemset(r->mean, 0, npix * 12)); HIP_TRY(hipMemset(r->cnt, 0, npix * 4)); HIP_TRY(hipMemset(r->rgb8, 0, npix * 3));
+    // on the renderer's own (non-blocking) stream: a null-stream memset would not be ordered before its kernels
+    HIP_TRY(hipMemsetAsync(r->mean, 0, npix * 12, r->stream)); HIP_TRY(hipMemsetAsync(r->cnt, 0, npix * 4, r->stream));
+    HIP_TRY(hipMemsetAsync(r->rgb8, 0, npix * 3, r->stream));
+    HIP_TRY(hipStreamSynchronize(r->stream));
     hipDeviceProp_t prop; HIP_TRY(hipGetDeviceProperties(&prop, scene->device));
+    HIP_TRY(dalloc((void**)&P.coop, (size_t)prop.multiProcessorCount * 8 * (kBlock / 64) * kCoopStride * sizeof(unsigned long long)));
     r->grid = prop.multiProcessorCount * 8;
+    {   // persistent extend kernel: LDS stack of (tree depth + 4) dwords per lane; grid = resident blocks only
+        const int entries = std::min(kStackSize, std::max(8, scene->max_depth + 4));
+        r->extend_lds = (size_t)entries * kBlock * 4;
+        const int by_lds = (int)((size_t)160 * 1024 / r->extend_lds), by_vgpr = 5;
+        r->extend_grid = prop.multiProcessorCount * std::max(1, std::min(by_lds, by_vgpr));
+    }
+    if (const char* e = getenv("MI355PT_EXTEND_BLOCKS_PER_CU")) r->extend_grid = prop.multiProcessorCount * std::max(1, atoi(e));
     r->count_work = getenv("MI355PT_COUNT_WORK") != nullptr;
+    if (const char* e = getenv("MI355PT_LONG_RAY")) r->long_ray = (uint32_t)strtoul(e, nullptr, 10);
     *out = r.release();
     return MI355PT_OK;
 }
@@ -724,19 +950,22 @@ void drain_events(mi355pt_render* r) {
 }
 
 // The bounce loop for `n` initialised path slots.
-int run_paths(mi355pt_render* r, uint32_t n) {
+int run_paths(mi355pt_render* r, uint32_t n, uint32_t jitter = 1, uint32_t only_extend = 0) {
     DPaths& P = r->P; const mi355pt_render_params& p = r->prm;
     const DScene& S = r->scene->d;
-    Params prm{p.seed, p.width, p.height, p.max_bounces, p.rr_start};
+    Params prm{p.seed, p.width, p.height, p.max_bounces, p.rr_start, r->long_ray};
     const size_t nb = p.max_bounces + 2;
     HIP_TRY(hipMemsetAsync(P.counts, 0, nb * 4, r->stream));
     HIP_TRY(hipMemsetAsync(P.scounts, 0, nb * 4, r->stream));
+    HIP_TRY(hipMemsetAsync(P.work, 0, nb * 4, r->stream));
     const int g = grid_for(r, n);
-    for (uint32_t b = 0; b < p.max_bounces; b++) {
+    const int ge = (int)std::min<size_t>((size_t)g, (size_t)r->extend_grid);     // persistent: resident waves only
+    for (uint32_t b = 0; b < (only_extend ? 1u : p.max_bounces); b++) {
         ev_begin(r, 0);
-        if (r->count_work) hipLaunchKernelGGL(k_extend<true>, dim3(g), dim3(kBlock), 0, r->stream, S, r->cam, P, prm, b, n);
-        else hipLaunchKernelGGL(k_extend<false>, dim3(g), dim3(kBlock), 0, r->stream, S, r->cam, P, prm, b, n);
+        if (r->count_work) hipLaunchKernelGGL(k_extend<true>, dim3(ge), dim3(kBlock), r->extend_lds, r->stream, S, r->cam, P, prm, b, n, jitter);
+        else hipLaunchKernelGGL(k_extend<false>, dim3(ge), dim3(kBlock), r->extend_lds, r->stream, S, r->cam, P, prm, b, n, jitter);
         ev_end(r);
+        if (only_extend) break;
         ev_begin(r, 1);
         hipLaunchKernelGGL(k_shade, dim3(g), dim3(kBlock), 0, r->stream, S, r->cam, P, prm, b, n);
         ev_end(r);
@@ -745,7 +974,7 @@ int run_paths(mi355pt_render* r, uint32_t n) {
         else hipLaunchKernelGGL(k_connect<false>, dim3(g), dim3(kBlock), 0, r->stream, S, P, b);
         ev_end(r);
     }
-    hipLaunchKernelGGL(k_stats, dim3(1), dim3(64), 0, r->stream, P, n, p.max_bounces);
+    if (!only_extend) hipLaunchKernelGGL(k_stats, dim3(1), dim3(64), 0, r->stream, P, n, p.max_bounces);
     HIP_TRY(hipGetLastError());
     return MI355PT_OK;
 }
@@ -761,7 +990,7 @@ int mi355pt_render_step(mi355pt_render* r, uint32_t spp) {
     const size_t npix = (size_t)p.width * p.height, cap = r->P.cap;
     const size_t ppc = std::min(npix, cap);
     const size_t spc = ppc == npix ? std::max<size_t>(1, cap / npix) : 1;
-    const Params kprm{p.seed, p.width, p.height, p.max_bounces, p.rr_start};
+    const Params kprm{p.seed, p.width, p.height, p.max_bounces, p.rr_start, r->long_ray};
     for (size_t pix_base = 0; pix_base < npix; pix_base += ppc) {
         const uint32_t np = (uint32_t)std::min(ppc, npix - pix_base);
         for (uint32_t s0 = 0; s0 < spp; s0 += (uint32_t)spc) {
@@ -826,15 +1055,46 @@ int mi355pt_trace_primary(mi355pt_render* r, uint32_t x0, uint32_t y0, uint32_t 
     int32_t *dn, *dm, *df; float* dt;
     HIP_TRY(hipMalloc((void**)&dn, n * 4)); HIP_TRY(hipMalloc((void**)&dm, n * 4)); HIP_TRY(hipMalloc((void**)&df, n * 4)); HIP_TRY(hipMalloc((void**)&dt, n * 4));
     const mi355pt_render_params& p = r->prm;
-    Params prm{p.seed, p.width, p.height, p.max_bounces, p.rr_start};
-    if (r->count_work) hipLaunchKernelGGL(k_primary<true>, dim3(grid_for(r, n)), dim3(kBlock), 0, r->stream, r->scene->d, r->cam, prm, x0, y0, rw, rh, dn, dm, df, dt, r->P.stat);
-    else hipLaunchKernelGGL(k_primary<false>, dim3(grid_for(r, n)), dim3(kBlock), 0, r->stream, r->scene->d, r->cam, prm, x0, y0, rw, rh, dn, dm, df, dt, r->P.stat);
+    Params prm{p.seed, p.width, p.height, p.max_bounces, p.rr_start, r->long_ray};
+    if (n > r->P.cap) { (void)hipFree(dn); (void)hipFree(dm); (void)hipFree(df); (void)hipFree(dt); return fail(MI355PT_ERR_TOO_LARGE, "rectangle larger than the path pool"); }
+    hipLaunchKernelGGL(k_primary_init, dim3(grid_for(r, n)), dim3(kBlock), 0, r->stream, r->P, prm, x0, y0, rw, rh);
+    const int rc = run_paths(r, (uint32_t)n, 0, 1);
+    hipLaunchKernelGGL(k_primary_out, dim3(grid_for(r, n)), dim3(kBlock), 0, r->stream, r->scene->d, r->P, (uint32_t)n, dn, dm, df, dt);
+    (void)rc;
     hipError_t e = hipStreamSynchronize(r->stream);
     if (e == hipSuccess) e = hipMemcpy(node, dn, n * 4, hipMemcpyDeviceToHost);
     if (e == hipSuccess) e = hipMemcpy(mesh, dm, n * 4, hipMemcpyDeviceToHost);
     if (e == hipSuccess) e = hipMemcpy(face, df, n * 4, hipMemcpyDeviceToHost);
     if (e == hipSuccess) e = hipMemcpy(t, dt, n * 4, hipMemcpyDeviceToHost);
     (void)hipFree(dn); (void)hipFree(dm); (void)hipFree(df); (void)hipFree(dt);
+    HIP_TRY(e);
+    return MI355PT_OK;
+}
+
+int mi355pt_trace_rays(mi355pt_render* r, const float* origins, const float* dirs, uint32_t count, int32_t* node, int32_t* mesh, int32_t* face, float* t) {
+    if (!r || !origins || !dirs || !node || !mesh || !face || !t) return fail(MI355PT_ERR_INVALID, "null argument");
+    if (count == 0) return MI355PT_OK;
+    if (count > r->P.cap) return fail(MI355PT_ERR_TOO_LARGE, "more rays than path slots");
+    HIP_TRY(hipSetDevice(r->scene->device));
+    const size_t n = count, cap = r->P.cap;
+    int32_t *dn, *dm, *df; float* dt;
+    HIP_TRY(hipMalloc((void**)&dn, n * 4)); HIP_TRY(hipMalloc((void**)&dm, n * 4)); HIP_TRY(hipMalloc((void**)&df, n * 4)); HIP_TRY(hipMalloc((void**)&dt, n * 4));
+    std::vector<float> soa(6 * n);
+    for (size_t i = 0; i < n; i++) for (int c = 0; c < 3; c++) { soa[c * n + i] = origins[3 * i + c]; soa[(3 + c) * n + i] = dirs[3 * i + c]; }
+    hipError_t e = hipSuccess;
+    for (int c = 0; c < 6 && e == hipSuccess; c++) e = hipMemcpy(r->P.ray + c * cap, soa.data() + c * n, n * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        const int rc = run_paths(r, (uint32_t)n, 2, 1);
+        (void)rc;
+        hipLaunchKernelGGL(k_primary_out, dim3(grid_for(r, n)), dim3(kBlock), 0, r->stream, r->scene->d, r->P, (uint32_t)n, dn, dm, df, dt);
+        e = hipStreamSynchronize(r->stream);
+    }
+    if (e == hipSuccess) e = hipMemcpy(node, dn, n * 4, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(mesh, dm, n * 4, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(face, df, n * 4, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(t, dt, n * 4, hipMemcpyDeviceToHost);
+    (void)hipFree(dn); (void)hipFree(dm); (void)hipFree(df); (void)hipFree(dt);
+    drain_events(r);
     HIP_TRY(e);
     return MI355PT_OK;
 }
@@ -851,7 +1111,7 @@ int mi355pt_sample_radiance(mi355pt_render* r, const uint32_t* pixel, const uint
     HIP_TRY(hipMalloc((void**)&dl, (size_t)count * 12)); HIP_TRY(hipMalloc((void**)&dm, (size_t)count * 12));
     HIP_TRY(hipMemcpy(dp, pixel, (size_t)count * 4, hipMemcpyHostToDevice)); HIP_TRY(hipMemcpy(ds, sample, (size_t)count * 4, hipMemcpyHostToDevice));
     const mi355pt_render_params& p = r->prm;
-    const Params kprm{p.seed, p.width, p.height, p.max_bounces, p.rr_start};
+    const Params kprm{p.seed, p.width, p.height, p.max_bounces, p.rr_start, r->long_ray};
     hipLaunchKernelGGL(k_init, dim3(grid_for(r, count)), dim3(kBlock), 0, r->stream, r->P, kprm,
                        count, 0u, 1u, (const uint32_t*)r->cnt, 0u, 1u, (const uint32_t*)dp, (const uint32_t*)ds);
     int rc = run_paths(r, count);
@@ -872,7 +1132,7 @@ int mi355pt_render_stats(mi355pt_render* r, mi355pt_stats* st) {
     unsigned long long h[8];
     HIP_TRY(hipMemcpy(h, r->P.stat, sizeof(h), hipMemcpyDeviceToHost));
     st->closest_rays = h[0]; st->shadow_rays = h[1]; st->samples = h[2]; st->bvh_node_visits = h[3]; st->bvh_tri_tests = h[4];
-    st->shadow_node_visits = h[5]; st->shadow_tri_tests = h[6];
+    st->shadow_node_visits = h[5]; st->shadow_tri_tests = h[6]; st->max_nodes_per_ray = h[7];
     st->extend_ms = r->ms[0]; st->shade_ms = r->ms[1]; st->connect_ms = r->ms[2]; st->other_ms = r->ms[3];
     st->extend_launches = r->extend_launches;
     return MI355PT_OK;
@@ -880,7 +1140,8 @@ int mi355pt_render_stats(mi355pt_render* r, mi355pt_stats* st) {
 int mi355pt_render_reset_stats(mi355pt_render* r) {
     if (!r) return fail(MI355PT_ERR_INVALID, "null argument");
     if (int rc = mi355pt_render_sync(r)) return rc;
-    HIP_TRY(hipMemset(r->P.stat, 0, 8 * sizeof(unsigned long long)));
+    HIP_TRY(hipMemsetAsync(r->P.stat, 0, 8 * sizeof(unsigned long long), r->stream));
+    HIP_TRY(hipStreamSynchronize(r->stream));
     for (double& m : r->ms) m = 0;
     r->extend_launches = 0;
     return MI355PT_OK;

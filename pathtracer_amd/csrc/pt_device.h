@@ -165,6 +165,14 @@ PT_DEV bool slab(const float* b, F3 p, F3 inv, float& tnear) {
     return true;
 }
 
+// Pruning guard.  The reference has no distance culling at all (bvh.h:88-129 ignores t); skipping a
+// subtree whose slab entry distance lies beyond the best hit is exact in real arithmetic, but the
+// triangle's t (plane equation, cancellation ~ eps * |o| / cos) and the slab's entry distance round
+// differently, so the cull keeps a margin far above either error: a subtree is skipped only when
+// tnear > bt * (1 + 1e-4) + 1e-4 * |o|_1.  Cost: a handful of extra node visits per thousand.
+PT_DEV float prune_abs(F3 o) { return 1e-4f * (fabsf(o.x) + fabsf(o.y) + fabsf(o.z)); }
+PT_DEV bool beyond(float tnear, float bt, float pabs) { return tnear > bt * 1.0001f + pabs; }
+
 // ------------------------------------------------------------------ triangle (model.h:227-347)
 struct Tri { F3 v0, v1, v2; uint32_t face; };
 PT_DEV Tri load_tri(const float4* tris, uint32_t slot) {
@@ -263,62 +271,82 @@ PT_DEV bool tri_any_front(const Tri& T, F3 o, F3 d, float bound) {
 // a node's bound is tested only when the node is internal; leaf faces are all tested; the result
 // is the minimum in (t, slot) order == the reference's exhaustive recursion with its tie rules
 // (src/model.cpp:4-163).  Pruning uses the slab entry distance against the running best.
-constexpr int kStackSize = 64;
+constexpr int kStackSize = 48;        // entries per lane; host checks tree depth + 4 <= kStackSize
+constexpr int kTravBlock = 256;       // threads per block of every kernel that traverses
+constexpr uint32_t kLeafFlag = 0x80000000u, kLeafSlotMask = 0x07FFFFFFu;   // leaf entry: flag | count<<27 | first slot
 struct WorkCounters { uint32_t nodes, tris; };
 
+// Traversal stack: node / leaf references live in LDS (one dword per entry, entry e of lane l at
+// lds[e * kTravBlock + l]: consecutive lanes hit consecutive banks, conflict-free), the entry
+// distances used for the pop-time cull live in a private array that is read in the shadow of the
+// node fetch (the fetch is issued first).  The loop is "while-while": every lane walks internal
+// nodes until it holds a leaf, then the wave tests triangles together, so the expensive
+// bit-exact triangle test runs with most lanes active.
 template <bool ANY, bool COUNT>
-PT_DEV bool traverse_mesh(const DScene& S, const DMesh& M, F3 o, F3 d, F3 inv, int side, float& bt, uint32_t& bslot, WorkCounters& wc) {
+PT_DEV bool traverse_mesh(const DScene& S, const DMesh& M, F3 o, F3 d, F3 inv, int side, float& bt, uint32_t& bslot, WorkCounters& wc,
+                          uint32_t* lds) {
     // ANY: bt is the (fixed) bound; returns true on the first accepted front-face hit.
     // !ANY: (bt, bslot) updated; returns true if it changed.
+#define PT_STK(i) lds[(i) * kTravBlock]
     bool changed = false;
-    uint32_t stack_n[kStackSize];
     float stack_t[kStackSize];
+    const float pabs = prune_abs(o);
     int sp = 0;
-    uint32_t leaf_first[2]; uint32_t leaf_cnt[2]; int nleaf = 0;
+    auto push_leaf = [&](uint32_t first, uint32_t cnt) {
+        while (cnt) {
+            const uint32_t c = cnt > 15u ? 15u : cnt;
+            if (sp < kStackSize) { PT_STK(sp) = kLeafFlag | (c << 27) | first; sp++; }
+            first += c; cnt -= c;
+        }
+    };
     if (M.root_cnt == 0xFFFFFFFFu) {
         float tn;
         if (COUNT) wc.nodes++;
         if (!slab(M.root_bound, o, inv, tn)) return false;
-        stack_n[sp] = M.root_ref; stack_t[sp] = -kBig; sp++;
+        PT_STK(0) = M.root_ref; stack_t[0] = -kBig; sp = 1;
     } else {
-        leaf_first[0] = M.root_ref; leaf_cnt[0] = M.root_cnt; nleaf = 1;
+        push_leaf(M.root_ref, M.root_cnt);
     }
     for (;;) {
-        for (int l = 0; l < nleaf; l++) {
-            for (uint32_t k = 0; k < leaf_cnt[l]; k++) {
-                const uint32_t slot = leaf_first[l] + k;
-                const Tri T = load_tri(S.tris, slot);
-                if (COUNT) wc.tris++;
-                if (ANY) { if (tri_any_front(T, o, d, bt)) return true; }
-                else changed |= tri_closest(T, o, d, side, slot, bt, bslot);
-            }
-        }
-        nleaf = 0;
-        if (sp == 0) break;
-        sp--;
-        const uint32_t ni = stack_n[sp];
-        if (stack_t[sp] > bt) continue;          // pruned by a hit found since the push
-        const float4* np = S.bvh_nodes + 4 * (size_t)ni;
-        const float4 w0 = np[0], w1 = np[1], w2 = np[2], w3 = np[3];
-        if (COUNT) wc.nodes++;
-        const float lb[6] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y};
-        const float rb[6] = {w1.z, w1.w, w2.x, w2.y, w2.z, w2.w};
-        const uint32_t lref = __float_as_uint(w3.x), rref = __float_as_uint(w3.y), lcnt = __float_as_uint(w3.z), rcnt = __float_as_uint(w3.w);
-        float tl = -kBig, tr = -kBig;
-        bool hl = true, hr = true;
-        if (lcnt == 0xFFFFFFFFu) { hl = slab(lb, o, inv, tl); if (tl > bt) hl = false; }
-        else { leaf_first[nleaf] = lref; leaf_cnt[nleaf] = lcnt; nleaf++; hl = false; }
-        if (rcnt == 0xFFFFFFFFu) { hr = slab(rb, o, inv, tr); if (tr > bt) hr = false; }
-        else { leaf_first[nleaf] = rref; leaf_cnt[nleaf] = rcnt; nleaf++; hr = false; }
-        if (hl && hr) {
+        uint32_t lf = 0, lc = 0;
+        while (sp > 0) {
+            sp--;
+            const uint32_t e = PT_STK(sp);
+            if (e & kLeafFlag) { lf = e & kLeafSlotMask; lc = (e >> 27) & 15u; break; }
+            const float4* np = S.bvh_nodes + 4 * (size_t)e;
+            const float4 w0 = np[0], w1 = np[1], w2 = np[2], w3 = np[3];
+            if (beyond(stack_t[sp], bt, pabs)) continue;          // pruned by a hit found since the push
+            if (COUNT) wc.nodes++;
+            const float lb[6] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y};
+            const float rb[6] = {w1.z, w1.w, w2.x, w2.y, w2.z, w2.w};
+            const uint32_t lref = __float_as_uint(w3.x), rref = __float_as_uint(w3.y), lcnt = __float_as_uint(w3.z), rcnt = __float_as_uint(w3.w);
+            float tl = -kBig, tr = -kBig;
+            bool hl = false, hr = false;
+            if (lcnt == 0xFFFFFFFFu) { hl = slab(lb, o, inv, tl); if (beyond(tl, bt, pabs)) hl = false; }
+            if (rcnt == 0xFFFFFFFFu) { hr = slab(rb, o, inv, tr); if (beyond(tr, bt, pabs)) hr = false; }
+            // internal children: far first, so the near one is popped first; leaves last, so they are
+            // popped before either (cheap, and they shrink the pruning distance early)
             const bool left_first = !(tr < tl);
-            if (sp + 2 <= kStackSize) {
-                if (left_first) { stack_n[sp] = rref; stack_t[sp] = tr; sp++; stack_n[sp] = lref; stack_t[sp] = tl; sp++; }
-                else { stack_n[sp] = lref; stack_t[sp] = tl; sp++; stack_n[sp] = rref; stack_t[sp] = tr; sp++; }
-            }
-        } else if (hl) { if (sp < kStackSize) { stack_n[sp] = lref; stack_t[sp] = tl; sp++; } }
-        else if (hr) { if (sp < kStackSize) { stack_n[sp] = rref; stack_t[sp] = tr; sp++; } }
+            if (hl && hr) {
+                if (sp + 2 <= kStackSize) {
+                    if (left_first) { PT_STK(sp) = rref; stack_t[sp] = tr; sp++; PT_STK(sp) = lref; stack_t[sp] = tl; sp++; }
+                    else { PT_STK(sp) = lref; stack_t[sp] = tl; sp++; PT_STK(sp) = rref; stack_t[sp] = tr; sp++; }
+                }
+            } else if (hl) { if (sp < kStackSize) { PT_STK(sp) = lref; stack_t[sp] = tl; sp++; } }
+            else if (hr) { if (sp < kStackSize) { PT_STK(sp) = rref; stack_t[sp] = tr; sp++; } }
+            if (lcnt != 0xFFFFFFFFu) push_leaf(lref, lcnt);
+            if (rcnt != 0xFFFFFFFFu) push_leaf(rref, rcnt);
+        }
+        if (lc == 0) { if (sp == 0) break; else continue; }
+        for (uint32_t k = 0; k < lc; k++) {
+            const uint32_t slot = lf + k;
+            const Tri T = load_tri(S.tris, slot);
+            if (COUNT) wc.tris++;
+            if (ANY) { if (tri_any_front(T, o, d, bt)) return true; }
+            else changed |= tri_closest(T, o, d, side, slot, bt, bslot);
+        }
     }
+#undef PT_STK
     return ANY ? false : changed;
 }
 
@@ -344,7 +372,7 @@ PT_DEV bool plane_hit(F3 o, F3 d, int side, float& t, bool& front, F3& P) {
 struct HitRec { float t; int inst; int mesh; uint32_t slot; };
 
 template <bool COUNT>
-PT_DEV HitRec trace_closest(const DScene& S, const Ray& wr, WorkCounters& wc) {
+PT_DEV HitRec trace_closest(const DScene& S, const Ray& wr, WorkCounters& wc, uint32_t* lds) {
     HitRec best; best.t = kBig; best.inst = -1; best.mesh = -1; best.slot = 0;
     for (int ii = 0; ii < S.num_insts; ii++) {
         const DInst& in = S.insts[ii];
@@ -365,7 +393,7 @@ PT_DEV HitRec trace_closest(const DScene& S, const Ray& wr, WorkCounters& wc) {
                 // and only a strictly closer one replaces it.
                 float bt = best.t; uint32_t bslot = 0;
                 bool ch;
-                ch = traverse_mesh<false, COUNT>(S, M, lr.p, lr.d, inv, SIDE_BOTH, bt, bslot, wc);
+                ch = traverse_mesh<false, COUNT>(S, M, lr.p, lr.d, inv, SIDE_BOTH, bt, bslot, wc, lds);
                 if (ch) { best.t = bt; best.inst = ii; best.mesh = mi; best.slot = bslot; }
             }
         }

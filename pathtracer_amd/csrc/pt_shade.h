@@ -435,7 +435,7 @@ PT_DEV float light_pdf(const DLight& L, F3 hitp, F3 sp, F3 sn, float distance) {
 // LightVisTest (raytracer.cpp:67-152).  Returns true when BLOCKED; on "not blocked" lp/ln hold the
 // light hit point / normal in world space.
 template <bool COUNT>
-PT_DEV bool light_vis_test(const DScene& S, const Ray& wr, float tmax, const DLight& L, F3& lp, F3& ln, WorkCounters& wc) {
+PT_DEV bool light_vis_test(const DScene& S, const Ray& wr, float tmax, const DLight& L, F3& lp, F3& ln, WorkCounters& wc, uint32_t* lds) {
     // (1) the light's own object, both sides
     const DInst& li = S.insts[L.inst];
     const Ray lr = to_inst(S, li, wr);
@@ -466,7 +466,7 @@ PT_DEV bool light_vis_test(const DScene& S, const Ray& wr, float tmax, const DLi
                 const DMesh& M = S.meshes[mo.first_mesh + mi];
                 if (!slab(M.aabb, r.p, inv, tn)) continue;
                 float b = bound; uint32_t dummy = 0;
-                if (traverse_mesh<true, COUNT>(S, M, r.p, r.d, inv, SIDE_FRONT, b, dummy, wc)) return true;
+                if (traverse_mesh<true, COUNT>(S, M, r.p, r.d, inv, SIDE_FRONT, b, dummy, wc, lds)) return true;
             }
         }
     }

@@ -134,6 +134,16 @@ class PathTracer:
                                                             face.ctypes.data, t.ctypes.data), "trace_primary")
         return node, mesh, face, t
 
+    def trace_rays(self, origins, dirs):
+        origins = np.ascontiguousarray(origins, dtype=np.float32)
+        dirs = np.ascontiguousarray(dirs, dtype=np.float32)
+        n = origins.shape[0]
+        node, mesh, face = (np.zeros(n, dtype=np.int32) for _ in range(3))
+        t = np.zeros(n, dtype=np.float32)
+        capi.check(self.lib, self.lib.mi355pt_trace_rays(self.h, origins.ctypes.data, dirs.ctypes.data, n, node.ctypes.data,
+                                                         mesh.ctypes.data, face.ctypes.data, t.ctypes.data), "trace_rays")
+        return node, mesh, face, t
+
     def sample_radiance(self, pixel, sample):
         pixel = np.ascontiguousarray(pixel, dtype=np.uint32)
         sample = np.ascontiguousarray(sample, dtype=np.uint32)

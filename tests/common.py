@@ -54,3 +54,23 @@ def rel_mse(a, b):
     """relMSE = mean (a-b)^2 / (b^2 + 1e-2)  (SURVEY 8d)."""
     a = a.astype(np.float64); b = b.astype(np.float64)
     return float(np.mean((a - b) ** 2 / (b ** 2 + 1e-2)))
+
+
+def attach_product_bvh(s, dscene):
+    """Hand the BVH the product built to the scene's meshes, so that the oracle imports it instead of
+    running its literal O(153 N depth) builder (only for meshes too large for that; the two builders
+    are compared node for node on every small mesh)."""
+    import ctypes as C
+    mi = 0
+
+    def walk(n):
+        nonlocal mi
+        if n.obj is not None and getattr(n.obj, "meshes", None):
+            for m in n.obj.meshes:
+                nodes, faces, nn = dscene.get_bvh(mi)
+                m.bvh_nodes = (capi.BvhNode * nn).from_buffer_copy(bytes(nodes)[:nn * C.sizeof(capi.BvhNode)])
+                m.bvh_faces = np.ascontiguousarray(faces)
+                mi += 1
+        for c in n.children:
+            walk(c)
+    walk(s.rootNode)
