@@ -143,18 +143,26 @@ __global__ void __launch_bounds__(kBlock) k_extend(DScene S, DCamera cam, DPaths
     F3 inv = f3(0, 0, 0);
     HitRec best; best.t = kBig; best.inst = -1; best.mesh = -1; best.slot = 0;
     uint32_t ray_nodes = 0, steps = 0;
+    // queue chunk per atomic: large while there is plenty of work per wave, 64 when the queue is short
+    const uint32_t nwaves = gridDim.x * (kBlock / 64);
+    uint32_t chunk = (n / (8u * nwaves)) & ~63u; chunk = chunk < 64u ? 64u : (chunk > 1024u ? 1024u : chunk);
+    uint32_t pool_next = 0, pool_end = 0; bool exhausted = false;
     unsigned long long* coop = P.coop + (size_t)(blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6)) * kCoopStride;
     for (;;) {
-        // ---- refill idle lanes
+        // ---- refill idle lanes from the wave's chunk of the queue; one atomic on the global counter per chunk
+        // (a per-refill atomic made every wave of the chip serialise on one L2 address)
         const unsigned long long need = __ballot(state == ST_FETCH);
         if (need) {
-            const int leader = __ffsll((long long)need) - 1;
-            uint32_t base = 0;
-            if (lane == leader) base = atomicAdd(work, (uint32_t)__popcll(need));
-            base = __shfl(base, leader);
+            if (pool_next >= pool_end && !exhausted) {
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(work, chunk);
+                base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+                if (base >= n) { exhausted = true; pool_next = pool_end = n; }
+                else { pool_next = base; pool_end = base + chunk < n ? base + chunk : n; }
+            }
             if (state == ST_FETCH) {
-                const uint32_t idx = base + (uint32_t)__popcll(need & ((1ull << lane) - 1ull));
-                if (idx < n) {
+                const uint32_t idx = pool_next + (uint32_t)__popcll(need & ((1ull << lane) - 1ull));
+                if (idx < pool_end) {
                     slot = q ? q[idx] : idx;
                     if (bounce == 0 && jitter != 2) { F3 rd, td; camera_rays(cam, prm.seed, P.pix[slot], P.smp[slot], prm.width, jitter != 0, wr, rd, td); }
                     else { wr.p = f3(P.ray[slot], P.ray[cap + slot], P.ray[2 * cap + slot]);
@@ -162,8 +170,10 @@ __global__ void __launch_bounds__(kBlock) k_extend(DScene S, DCamera cam, DPaths
                     best.t = kBig; best.inst = -1; best.mesh = -1; best.slot = 0;
                     ii = 0; state = ST_INST;
                     if (COUNT) ray_nodes = 0;
-                } else state = ST_DONE;
+                } else if (exhausted) state = ST_DONE;      // otherwise: wait for the next chunk
             }
+            const uint32_t took = (uint32_t)__popcll(need);
+            pool_next = pool_end - pool_next < took ? pool_end : pool_next + took;
         }
         if (__ballot(state != ST_DONE) == 0) break;
         // ---- next object of the scene graph (TraceNode, raytracer.cpp:189-258: earlier object wins ties)

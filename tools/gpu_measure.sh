@@ -1,0 +1,15 @@
+#!/bin/bash
+# Round measurement on the GPU box: bench line, kernel-trace stats, and the two HBM-traffic PMC passes.
+# Usage (through gpurun, from the repo root): bash tools/gpu_measure.sh <tag>
+set -o pipefail
+tag=${1:-r01}
+out=$PWD/gpurun_out/$tag
+mkdir -p $out
+export TMPDIR=/tmp
+timeout -k 10 420 python3 bench.py > $out/bench.json 2> $out/bench.err || exit 1
+tail -c 3000 $out/bench.json
+cd /tmp
+timeout -k 10 240 rocprofv3 --kernel-trace --stats -d $out/trace -o trace -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-roofline > $out/trace.log 2>&1 || exit 2
+timeout -s KILL 200 rocprofv3 --pmc FETCH_SIZE -d $out/pmc_fetch -o pmc -- python3 $GRAFT_REPO_ROOT/tools/prof_step.py 30 2 > $out/pmc_fetch.log 2>&1 || exit 3
+timeout -s KILL 200 rocprofv3 --pmc WRITE_SIZE -d $out/pmc_write -o pmc -- python3 $GRAFT_REPO_ROOT/tools/prof_step.py 30 2 > $out/pmc_write.log 2>&1 || exit 4
+find $out -name '*.csv' | head -20
