@@ -104,14 +104,15 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     device = local_rank if world > 1 else 0
 
-    from pathtracer_amd import PathTracer, capi
+    from pathtracer_amd import PathTracer, capi, distributed
     lib = capi.load_library()
     if lib.mi355pt_device_count() < 1:
         raise SystemExit("bench.py needs a gfx950 device; there is no CPU fallback")
 
     t0 = time.perf_counter()
     scene, workload = build_scene(args)
-    pt = PathTracer(scene, device=device, seed=args.seed, sample_offset=rank, sample_stride=world)
+    off, stride = distributed.rank_sample_split(rank, world)
+    pt = PathTracer(scene, device=device, seed=args.seed, sample_offset=off, sample_stride=stride)
     pt.Init(args.width, args.height)
     if rank == 0:
         log(f"scene + BVH + upload: {time.perf_counter() - t0:.1f} s")
@@ -133,12 +134,9 @@ def main():
     for _ in range(args.steps):
         pt.step(1)
     pt.sync()
-    if dist is not None:            # combine the per-GPU running means: sum_g n_g c_g / sum_g n_g, one RCCL reduce
-        mean, cnt = pt.read_accum()
-        acc = torch.from_numpy(mean * cnt[:, None].astype(np.float32)).cuda()
-        n = torch.from_numpy(cnt.astype(np.float32)).cuda()
-        dist.reduce(acc, 0)
-        dist.reduce(n, 0)
+    if dist is not None:            # read-out: ONE RCCL reduce of (n*mean, n) per pixel, straight from the accumulators in HBM
+        mean_t, cnt_t = distributed.accum_tensors(pt)
+        combined = distributed.combine_running_means(mean_t, cnt_t, dist, 0)
     barrier()
     dt = time.perf_counter() - t0
     st = pt.stats()

@@ -11,17 +11,16 @@
 // library, and only as the checker / the timed CPU baseline.  The product
 // (pathtracer_amd/csrc) never links, includes or calls anything in oracle/.
 //
-// PARITY PIN STATUS: the full reference cannot be built in this image under the
-// round's rules (assimp needs a cmake-generated config.h; src/lightcomponent.cpp,
-// src/objects.cpp, src/raytracer.cpp, src/model.cpp do not compile with g++ from the
-// sources where they lie -- see DESIGN.md "Oracle").  The pieces of the reference that
-// DO compile in place (materials, BRDFs, texture filter, tone mapping, Halton, slab
-// test, node transforms, cy/glm arithmetic, lens/GGX sampling) are built into
-// oracle/_ref/libref_pieces.so and this restatement is checked against them
-// (tests/test_oracle_vs_ref_pieces.py, fixtures in tests/golden/).  The triangle test,
-// BVH builder, Plane test, light sampling, TraceNode/LightVisTest and the integrated
-// RenderPixel loop have no runnable reference here: for those, parity is UNPINNED and
-// rests on this restatement alone.
+// PARITY PIN STATUS: *** PARITY UNPINNED ***.  The reference holds no tests, golden
+// vectors or fixtures for this path, and it cannot be built in this
+// image from its own sources alone: assimp needs a cmake-generated config.h, several of
+// its translation units rely on MSVC extensions and a case-insensitive file system, and
+// an attempt to build the pieces that remain with compiler-flag workarounds was refused
+// by the environment as a stand-in build ("Oracle pin status").  This
+// restatement therefore rests on a line-by-line reading of the reference sources (each
+// function cites the file:line it follows) and on known-answer / property checks in
+// tests/test_oracle_properties.py; nothing here has been compared with output of the
+// reference itself.
 //
 // The only deliberate departure from the reference: libc rand() is replaced by the
 // counter-based generator pt_rng (keyed seed/pixel/sample/draw#), as north_star asks

@@ -1,0 +1,55 @@
+"""Multi-GPU work split and read-out for the progressive renderer.
+
+Every (pixel, sample) is independent given the immutable scene (src/pathtracer.cpp:70-108),
+so the path shards with no data-path collective: the scene is replicated, rank g renders
+sample indices g, g+G, g+2G, ... of every pixel.  The reference averages tone-mapped
+samples (pathtracer.cpp:86-90), so the per-pixel value is linear in the samples and the
+read-out is ONE exchange: sum_g n_g * mean_g and sum_g n_g, reduced to rank 0 (RCCL over
+xGMI when the tensors live in HBM; gloo in the CPU tests).
+"""
+import numpy as np
+
+
+def rank_sample_split(rank, world):
+    """(sample_offset, sample_stride) of a rank: samples rank, rank+world, ..."""
+    if not 0 <= rank < world:
+        raise ValueError(f"rank {rank} outside world {world}")
+    return rank, world
+
+
+class _DevArray:
+    """Zero-copy view of a device buffer for torch.as_tensor (CUDA array interface v2)."""
+
+    def __init__(self, ptr, shape, typestr):
+        self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": typestr, "data": (int(ptr), False), "version": 2}
+
+
+def accum_tensors(pt):
+    """The renderer's running-mean and count buffers as torch tensors aliasing HBM (no copy).
+    Call after `pt.sync()`: the buffers are written on the renderer's own stream."""
+    import torch
+    mean_ptr, cnt_ptr = pt.accum_device_ptrs()
+    mean = torch.as_tensor(_DevArray(mean_ptr, (pt.size, 3), "<f4"), device=f"cuda:{pt.dscene.device}")
+    cnt = torch.as_tensor(_DevArray(cnt_ptr, (pt.size,), "<i4"), device=f"cuda:{pt.dscene.device}")
+    return mean, cnt
+
+
+def combine_running_means(mean, cnt, dist=None, dst=0):
+    """mean: (P,3) float tensor, cnt: (P,) integer tensor of one rank.  Returns on `dst` the
+    combined (mean, cnt) over all ranks, None elsewhere.  One reduce of 4 floats per pixel."""
+    import torch
+    n = cnt.to(torch.float32)
+    packed = torch.cat([mean.to(torch.float32) * n[:, None], n[:, None]], dim=1).contiguous()
+    if dist is not None and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.reduce(packed, dst, op=dist.ReduceOp.SUM)
+        if dist.get_rank() != dst:
+            return None
+    total = packed[:, 3]
+    out = packed[:, :3] / torch.clamp(total, min=1.0)[:, None]
+    return out, total.to(torch.int64)
+
+
+def resolve_rgb8(mean):
+    """uint8(mean * 255) truncating, as the reference writes renderImage (pathtracer.cpp:101)."""
+    m = np.asarray(mean, dtype=np.float32)
+    return (m * np.float32(255.0)).astype(np.uint8)

@@ -242,3 +242,29 @@ def test_secondary_rays_from_surfaces(built, name, long_ray, monkeypatch):
     assert np.array_equal(node, onode) and np.array_equal(mesh, omesh) and np.array_equal(face, oface)
     assert np.array_equal(t.view(np.uint32), ot.view(np.uint32))
     p2.close_render()
+
+
+@pytest.mark.parametrize("name", list(SCENES))
+def test_against_committed_golden_vectors(name):
+    """The HIP path against tests/golden/oracle_vectors.npz (frozen oracle outputs, made by
+    tests/golden/make_golden.py) -- no live oracle involved."""
+    import os
+    from tests.golden.make_golden import GW, GH, SEED
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "oracle_vectors.npz"))
+    mk, _, _ = SCENES[name]
+    s = mk(GW, GH)
+    pt = PathTracer(s, seed=SEED)
+    pt.Init(GW, GH)
+    node, mesh, face, t = pt.trace_primary()
+    assert np.array_equal(node, g[f"{name}/node"]) and np.array_equal(mesh, g[f"{name}/mesh"]) and np.array_equal(face, g[f"{name}/face"])
+    if s.camera.dof == 0.0:
+        assert np.array_equal(t.view(np.uint32), g[f"{name}/t"].view(np.uint32))
+    else:
+        assert np.all(np.abs(t - g[f"{name}/t"]) <= 1e-5 * np.abs(g[f"{name}/t"]))
+    lin, mp = pt.sample_radiance(g[f"{name}/pixel"], g[f"{name}/sample"])
+    frac, _ = common.radiance_agreement(lin, g[f"{name}/linear"])
+    assert frac >= 0.99, frac            # 256 pairs: allow 2 branch-flipped paths
+    pt.render(4)
+    mean, cnt = pt.read_accum()
+    assert common.rel_mse(mean, g[f"{name}/mean4"]) <= 1e-3
+    pt.close_render()
