@@ -191,6 +191,7 @@ typedef struct mi355pt_stats {
     double   connect_ms;
     double   other_ms;
     uint64_t extend_launches;
+    uint64_t debug[8];          /* counting builds: kernel-internal utilisation counters */
 } mi355pt_stats;
 
 typedef struct mi355pt_scene  mi355pt_scene;    /* opaque: flattened scene in HBM      */

@@ -85,7 +85,7 @@ class RenderParams(C.Structure):
 class Stats(C.Structure):
     _fields_ = [("closest_rays", u64), ("shadow_rays", u64), ("samples", u64), ("bvh_node_visits", u64),
                 ("bvh_tri_tests", u64), ("shadow_node_visits", u64), ("shadow_tri_tests", u64), ("max_nodes_per_ray", u64), ("extend_ms", C.c_double), ("shade_ms", C.c_double),
-                ("connect_ms", C.c_double), ("other_ms", C.c_double), ("extend_launches", u64)]
+                ("connect_ms", C.c_double), ("other_ms", C.c_double), ("extend_launches", u64), ("debug", u64 * 8)]
 
 
 def make_params(width, height, seed=0x5EED, max_bounces=30, rr_start=3, sample_offset=0, sample_stride=1, device=0):
@@ -110,7 +110,7 @@ def load_library(path=None):
     global _lib
     if _lib is not None and path is None:
         return _lib
-    p = path or LIB_PATH
+    p = path or os.environ.get("MI355PT_LIBRARY") or LIB_PATH      # the override is for A/B runs of experimental builds
     if not os.path.exists(p):
         raise RuntimeError(
             f"{p} not found: the HIP backend has not been built (run `python __graft_entry__.py build`). "

@@ -48,7 +48,7 @@ struct DPaths {
     uint32_t *work;       // [b] = next queue index to hand out in k_extend of bounce b (persistent refill)
     unsigned long long *stat;   // [0] closest rays [1] shadow rays [2] samples [3,4] extend node visits / tri tests [5,6] connect ditto
 };
-struct Params { uint32_t seed, width, height, max_bounces, rr_start, long_ray; };
+struct Params { uint32_t seed, width, height, max_bounces, rr_start, long_ray, stack_entries; };
 
 #define PT_LD3(arr, cap, i) f3((arr)[(i)], (arr)[(size_t)(cap) + (i)], (arr)[2 * (size_t)(cap) + (i)])
 #define PT_ST3(arr, cap, i, v) do { (arr)[(i)] = (v).x; (arr)[(size_t)(cap) + (i)] = (v).y; (arr)[2 * (size_t)(cap) + (i)] = (v).z; } while (0)
@@ -106,7 +106,17 @@ __global__ void __launch_bounds__(kBlock) k_init(DPaths P, Params prm, uint32_t 
 // within a wave, node steps and the (expensive, bit-exact) triangle tests are run in separate
 // phases so that each executes with as many lanes active as possible.
 enum { ST_FETCH = 0, ST_INST, ST_MESH, ST_TRAV, ST_DONE };
+#ifndef PT_POPCULL
+#define PT_POPCULL 0     // re-testing an entry's distance when it is popped saved 1-2 % of node visits and cost a scratch array
+#endif
+#ifndef PT_EXT_WAVES
+#define PT_EXT_WAVES 3
+#endif
 constexpr int kNodeSteps = 4;
+constexpr int kLeafCap = 8;        // parked leaves per lane (LDS)
+constexpr int kTriEnter = 40;      // lanes with parked leaves that start a triangle phase
+constexpr int kTriExit = 16;       // ... and the count below which it yields to node steps again
+constexpr int kNodeMin = 12;       // with fewer lanes able to take a node step, test triangles instead
 // A ray that has taken more than kLongRay node steps in one mesh is finished by its whole wave:
 // the 64 lanes pop 64 entries of a shared (per-wave, global-memory) stack at a time.  This bounds the
 // kernel's tail -- the longest single traversal (thousands of dependent node fetches for a ray that
@@ -125,7 +135,7 @@ __device__ __forceinline__ unsigned long long coop_entry(uint32_t ref, float tne
 __device__ __forceinline__ F3 shfl3(F3 v, int j) { return f3(__shfl(v.x, j), __shfl(v.y, j), __shfl(v.z, j)); }
 
 template <bool COUNT>
-__global__ void __launch_bounds__(kBlock) k_extend(DScene S, DCamera cam, DPaths P, Params prm, uint32_t bounce, uint32_t n0, uint32_t jitter) {
+__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PT_EXT_WAVES, 8))) k_extend(DScene S, DCamera cam, DPaths P, Params prm, uint32_t bounce, uint32_t n0, uint32_t jitter) {
     const uint32_t n = bounce == 0 ? n0 : P.counts[bounce];
     const uint32_t* q = bounce == 0 ? nullptr : P.queue[bounce & 1];
     uint32_t* work = &P.work[bounce];
@@ -133,9 +143,19 @@ __global__ void __launch_bounds__(kBlock) k_extend(DScene S, DCamera cam, DPaths
     WorkCounters wc; wc.nodes = 0; wc.tris = 0;
     extern __shared__ uint32_t sm_stack[];       // stack_entries x kBlock dwords, sized by the host from the tree depth
 #define PT_STK(i) sm_stack[(i) * kBlock + threadIdx.x]
+#if PT_POPCULL
+#define PT_ST(i, v) stack_t[i] = (v)
+#define PT_GT(i) stack_t[i]
+#else
+#define PT_ST(i, v) do {} while (0)
+#define PT_GT(i) (-kBig)
+#endif
+#define PT_LSTK(i) sm_stack[(prm.stack_entries + (i)) * kBlock + threadIdx.x]
+#if PT_POPCULL
     float stack_t[kStackSize];
+#endif
     const int lane = __lane_id();
-    int state = ST_FETCH, ii = 0, mi = 0, sp = 0;
+    int state = ST_FETCH, ii = 0, mi = 0, sp = 0, ls = 0;
     uint32_t slot = 0, lf = 0, lc = 0, bslot = 0;
     float bt = 0.0f, pabs = 0.0f;
     bool changed = false;
@@ -148,7 +168,10 @@ __global__ void __launch_bounds__(kBlock) k_extend(DScene S, DCamera cam, DPaths
     uint32_t chunk = (n / (8u * nwaves)) & ~63u; chunk = chunk < 64u ? 64u : (chunk > 1024u ? 1024u : chunk);
     uint32_t pool_next = 0, pool_end = 0; bool exhausted = false;
     unsigned long long* coop = P.coop + (size_t)(blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6)) * kCoopStride;
+    unsigned long long dbg_outer = 0, dbg_node_it = 0, dbg_node_act = 0, dbg_tri_it = 0, dbg_tri_act = 0, dbg_coop = 0;
+    unsigned long long clk_node = 0, clk_load = 0, clk_tri = 0; const unsigned long long clk_begin = COUNT ? clock64() : 0;
     for (;;) {
+        if (COUNT) dbg_outer++;
         // ---- refill idle lanes from the wave's chunk of the queue; one atomic on the global counter per chunk
         // (a per-refill atomic made every wave of the chip serialise on one L2 address)
         const unsigned long long need = __ballot(state == ST_FETCH);
@@ -208,11 +231,11 @@ __global__ void __launch_bounds__(kBlock) k_extend(DScene S, DCamera cam, DPaths
                 if (!slab(M.aabb, lr.p, inv, tn)) mi++;
                 else {
                     // start from the global best with bslot = 0: an equal-t candidate of a later mesh / object loses
-                    bt = best.t; bslot = 0; changed = false; sp = 0; lc = 0; steps = 0;
+                    bt = best.t; bslot = 0; changed = false; sp = 0; lc = 0; ls = 0; steps = 0;
                     if (M.root_cnt == 0xFFFFFFFFu) {
                         if (COUNT) wc.nodes++;
                         if (!slab(M.root_bound, lr.p, inv, tn)) mi++;
-                        else { PT_STK(0) = M.root_ref; stack_t[0] = -kBig; sp = 1; state = ST_TRAV; }
+                        else { PT_STK(0) = M.root_ref; PT_ST(0, -kBig); sp = 1; state = ST_TRAV; }
                     } else {
                         uint32_t first = M.root_ref, cnt = M.root_cnt;
                         while (cnt) { const uint32_t c = cnt > 15u ? 15u : cnt; if (sp < kStackSize) { PT_STK(sp) = kLeafFlag | (c << 27) | first; sp++; } first += c; cnt -= c; }
@@ -232,14 +255,16 @@ __global__ void __launch_bounds__(kBlock) k_extend(DScene S, DCamera cam, DPaths
             bool gchanged = false;
             uint32_t sc = 0;
             if (lane == j) {                                  // lane j hands its private stack (and pending leaf) over
-                for (int k = 0; k < sp; k++) coop_store(&coop[k], coop_entry(PT_STK(k), stack_t[k]));
+                for (int k = 0; k < sp; k++) coop_store(&coop[k], coop_entry(PT_STK(k), PT_GT(k)));
                 sc = (uint32_t)sp;
                 if (lc > 0) { coop_store(&coop[sc], coop_entry(kLeafFlag | (lc << 27) | lf, -kBig)); sc++; }
-                sp = 0; lc = 0; steps = 0;
+                for (int k = 0; k < ls; k++) { coop_store(&coop[sc], coop_entry(PT_LSTK(k), -kBig)); sc++; }
+                sp = 0; lc = 0; ls = 0; steps = 0;
             }
             sc = __shfl(sc, j);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             while (sc > 0) {
+                if (COUNT) dbg_coop++;
                 uint32_t m = sc < 64u ? sc : 64u;
                 if (kCoopCap - sc < 4u * 64u) { const uint32_t room = (kCoopCap - sc) / 4u; m = room < m ? (room ? room : 1u) : m; }
                 const bool has = (uint32_t)lane < m;
@@ -287,10 +312,21 @@ __global__ void __launch_bounds__(kBlock) k_extend(DScene S, DCamera cam, DPaths
             }
             if (lane == j && gchanged) { bt = gbt; bslot = gslot; changed = true; }
         }
-        // ---- node phase: lanes without a pending leaf pop / visit up to kNodeSteps entries
+        // ---- phase choice.  Popped leaves are parked on a small per-lane leaf stack instead of being tested at
+        // once: triangle tests (3 x 16-B loads + the reference's full 3x3 inverse) are the expensive part, and
+        // testing them the moment one lane reaches a leaf ran that code with ~7 of 64 lanes active.  The
+        // triangle phase runs when enough lanes have parked leaves, or when nobody can take a node step.
+        const unsigned long long tri_m = __ballot(state == ST_TRAV && (lc > 0 || ls > 0));
+        const unsigned long long node_m = __ballot(state == ST_TRAV && lc == 0 && (sp > 0 ? ls + 2 <= kLeafCap : ls == 0));
+        const int ntri = __popcll(tri_m), nnode = __popcll(node_m);
+        const bool tri_phase = ntri > 0 && (ntri >= kTriEnter || nnode < kNodeMin);
+        const unsigned long long clk_p0 = COUNT ? clock64() : 0;
+        if (!tri_phase) {
+        // ---- node phase: up to kNodeSteps pops / visits per lane
         for (int it = 0; it < kNodeSteps; it++) {
-            const bool want = state == ST_TRAV && lc == 0;
+            const bool want = state == ST_TRAV && lc == 0 && (sp > 0 ? ls + 2 <= kLeafCap : ls == 0);
             if (__ballot(want) == 0) break;
+            if (COUNT) { dbg_node_it++; dbg_node_act += (unsigned long long)__popcll(__ballot(want)); }
             if (!want) continue;
             if (sp == 0) {                                  // this mesh is finished
                 if (changed) { best.t = bt; best.inst = ii; best.mesh = mi; best.slot = bslot; }
@@ -299,10 +335,14 @@ __global__ void __launch_bounds__(kBlock) k_extend(DScene S, DCamera cam, DPaths
             }
             sp--;
             const uint32_t e = PT_STK(sp);
-            if (e & kLeafFlag) { lf = e & kLeafSlotMask; lc = (e >> 27) & 15u; continue; }
+            if (e & kLeafFlag) { lf = e & kLeafSlotMask; lc = (e >> 27) & 15u; continue; }     // overflow path of the leaf stack
             const float4* np = S.bvh_nodes + 4 * (size_t)e;
+            const unsigned long long clk_l0 = COUNT ? clock64() : 0;
             const float4 w0 = np[0], w1 = np[1], w2 = np[2], w3 = np[3];
+            if (COUNT) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); clk_load += clock64() - clk_l0; }
+#if PT_POPCULL
             if (beyond(stack_t[sp], bt, pabs)) continue;    // pruned by a hit found since the push
+#endif
             if (COUNT) { wc.nodes++; ray_nodes++; }
             steps++;
             const float lb[6] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y};
@@ -315,28 +355,50 @@ __global__ void __launch_bounds__(kBlock) k_extend(DScene S, DCamera cam, DPaths
             const bool left_first = !(tr < tl);
             if (hl && hr) {
                 if (sp + 2 <= kStackSize) {
-                    if (left_first) { PT_STK(sp) = rref; stack_t[sp] = tr; sp++; PT_STK(sp) = lref; stack_t[sp] = tl; sp++; }
-                    else { PT_STK(sp) = lref; stack_t[sp] = tl; sp++; PT_STK(sp) = rref; stack_t[sp] = tr; sp++; }
+                    if (left_first) { PT_STK(sp) = rref; PT_ST(sp, tr); sp++; PT_STK(sp) = lref; PT_ST(sp, tl); sp++; }
+                    else { PT_STK(sp) = lref; PT_ST(sp, tl); sp++; PT_STK(sp) = rref; PT_ST(sp, tr); sp++; }
                 }
-            } else if (hl) { if (sp < kStackSize) { PT_STK(sp) = lref; stack_t[sp] = tl; sp++; } }
-            else if (hr) { if (sp < kStackSize) { PT_STK(sp) = rref; stack_t[sp] = tr; sp++; } }
-            // leaf children go on top: popped first (cheap, and they shrink the pruning distance early).
-            // The reference never tests a leaf's bound (model.cpp:6-25), so neither do we.
-            if (lcnt != 0xFFFFFFFFu) { uint32_t first = lref, cnt = lcnt; while (cnt) { const uint32_t c = cnt > 15u ? 15u : cnt; if (sp < kStackSize) { PT_STK(sp) = kLeafFlag | (c << 27) | first; sp++; } first += c; cnt -= c; } }
-            if (rcnt != 0xFFFFFFFFu) { uint32_t first = rref, cnt = rcnt; while (cnt) { const uint32_t c = cnt > 15u ? 15u : cnt; if (sp < kStackSize) { PT_STK(sp) = kLeafFlag | (c << 27) | first; sp++; } first += c; cnt -= c; } }
+            } else if (hl) { if (sp < kStackSize) { PT_STK(sp) = lref; PT_ST(sp, tl); sp++; } }
+            else if (hr) { if (sp < kStackSize) { PT_STK(sp) = rref; PT_ST(sp, tr); sp++; } }
+            // Leaf children are parked (the reference never tests a leaf's bound, model.cpp:6-25, so neither do we);
+            // a leaf of more than 15 triangles is split, the pieces beyond the leaf stack go on the node stack.
+            for (int c = 0; c < 2; c++) {
+                uint32_t first = c ? rref : lref, cnt = c ? rcnt : lcnt;
+                if (cnt == 0xFFFFFFFFu) continue;
+                while (cnt) {
+                    const uint32_t k = cnt > 15u ? 15u : cnt;
+                    const uint32_t ent = kLeafFlag | (k << 27) | first;
+                    if (ls < kLeafCap) { PT_LSTK(ls) = ent; ls++; }
+                    else if (sp < kStackSize) { PT_STK(sp) = ent; sp++; }
+                    first += k; cnt -= k;
+                }
+            }
         }
-        // ---- triangle phase: every lane holding a leaf tests its triangles
-        while (__ballot(state == ST_TRAV && lc > 0) != 0) {
-            if (state == ST_TRAV && lc > 0) {
+        if (COUNT) clk_node += clock64() - clk_p0;
+        } else {
+        // ---- triangle phase: every lane with a pending or parked leaf tests one triangle per pass
+        for (;;) {
+            if (lc == 0 && ls > 0 && state == ST_TRAV) { ls--; const uint32_t e = PT_LSTK(ls); lf = e & kLeafSlotMask; lc = (e >> 27) & 15u; }
+            const bool act = state == ST_TRAV && lc > 0;
+            const int nact = __popcll(__ballot(act));
+            if (nact == 0 || (nact < kTriExit && nnode >= kNodeMin)) break;
+            if (COUNT) { dbg_tri_it++; dbg_tri_act += (unsigned long long)nact; }
+            if (act) {
                 const Tri T = load_tri(S.tris, lf);
                 if (COUNT) wc.tris++;
                 changed |= tri_closest(T, lr.p, lr.d, SIDE_BOTH, lf, bt, bslot);
                 lf++; lc--;
             }
         }
+        if (COUNT) clk_tri += clock64() - clk_p0;
+        }
     }
 #undef PT_STK
-    if (COUNT) { wave_add64(wc.nodes, &P.stat[3]); wave_add64(wc.tris, &P.stat[4]); }
+#undef PT_LSTK
+    if (COUNT) { wave_add64(wc.nodes, &P.stat[3]); wave_add64(wc.tris, &P.stat[4]);
+        if (lane == 0) { atomicAdd(&P.stat[8], dbg_outer); atomicAdd(&P.stat[9], dbg_node_it); atomicAdd(&P.stat[10], dbg_node_act);
+                         atomicAdd(&P.stat[11], dbg_tri_it); atomicAdd(&P.stat[12], dbg_tri_act); atomicAdd(&P.stat[13], clk_load);
+                         atomicAdd(&P.stat[14], clk_node); atomicAdd(&P.stat[15], clk_tri); atomicAdd(&P.stat[8], (clock64() - clk_begin) << 32); } }
 }
 
 // ---------------------------------------------------------------------- shade
@@ -633,7 +695,7 @@ struct mi355pt_render {
     struct Ev { hipEvent_t a, b; int kind; };
     std::vector<Ev> events;
     double ms[4] = {0, 0, 0, 0}; uint64_t extend_launches = 0;
-    int grid = 2048, extend_grid = 768; size_t extend_lds = 0; uint32_t long_ray = kLongRayDefault;
+    int grid = 2048, extend_grid = 768; size_t extend_lds = 0; uint32_t long_ray = kLongRayDefault, stack_entries = 8;
     ~mi355pt_render() {
         for (auto& e : events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
         for (void* p : allocs) (void)hipFree(p);
@@ -901,8 +963,8 @@ int mi355pt_render_create(mi355pt_scene* scene, const mi355pt_render_params* par
     HIP_TRY(dalloc((void**)&P.queue[0], cap * 4)); HIP_TRY(dalloc((void**)&P.queue[1], cap * 4)); HIP_TRY(dalloc((void**)&P.squeue, cap * 4));
     const size_t nb = params->max_bounces + 2;
     HIP_TRY(dalloc((void**)&P.counts, nb * 4)); HIP_TRY(dalloc((void**)&P.scounts, nb * 4)); HIP_TRY(dalloc((void**)&P.work, nb * 4));
-    HIP_TRY(dalloc((void**)&P.stat, 8 * sizeof(unsigned long long)));
-    HIP_TRY(hipMemsetAsync(P.stat, 0, 8 * sizeof(unsigned long long), r->stream));
+    HIP_TRY(dalloc((void**)&P.stat, 16 * sizeof(unsigned long long)));
+    HIP_TRY(hipMemsetAsync(P.stat, 0, 16 * sizeof(unsigned long long), r->stream));
     HIP_TRY(dalloc((void**)&r->mean, npix * 12)); HIP_TRY(dalloc((void**)&r->cnt, npix * 4)); HIP_TRY(dalloc((void**)&r->rgb8, npix * 3));
     // on the renderer's own (non-blocking) stream: a null-stream memset would not be ordered before its kernels
     HIP_TRY(hipMemsetAsync(r->mean, 0, npix * 12, r->stream)); HIP_TRY(hipMemsetAsync(r->cnt, 0, npix * 4, r->stream));
@@ -913,12 +975,14 @@ int mi355pt_render_create(mi355pt_scene* scene, const mi355pt_render_params* par
     r->grid = prop.multiProcessorCount * 8;
     {   // persistent extend kernel: LDS stack of (tree depth + 4) dwords per lane; grid = resident blocks only
         const int entries = std::min(kStackSize, std::max(8, scene->max_depth + 4));
-        r->extend_lds = (size_t)entries * kBlock * 4;
+        r->stack_entries = (uint32_t)entries;
+        r->extend_lds = (size_t)(entries + kLeafCap) * kBlock * 4;
         const int by_lds = (int)((size_t)160 * 1024 / r->extend_lds), by_vgpr = 5;
         r->extend_grid = prop.multiProcessorCount * std::max(1, std::min(by_lds, by_vgpr));
     }
     if (const char* e = getenv("MI355PT_EXTEND_BLOCKS_PER_CU")) r->extend_grid = prop.multiProcessorCount * std::max(1, atoi(e));
     r->count_work = getenv("MI355PT_COUNT_WORK") != nullptr;
+    if (getenv("MI355PT_VERBOSE")) fprintf(stderr, "mi355pt: tree depth %d, extend grid %d blocks, LDS %zu B/block, long_ray %u\n", scene->max_depth, r->extend_grid, r->extend_lds, r->long_ray);
     if (const char* e = getenv("MI355PT_LONG_RAY")) r->long_ray = (uint32_t)strtoul(e, nullptr, 10);
     *out = r.release();
     return MI355PT_OK;
@@ -963,7 +1027,7 @@ void drain_events(mi355pt_render* r) {
 int run_paths(mi355pt_render* r, uint32_t n, uint32_t jitter = 1, uint32_t only_extend = 0) {
     DPaths& P = r->P; const mi355pt_render_params& p = r->prm;
     const DScene& S = r->scene->d;
-    Params prm{p.seed, p.width, p.height, p.max_bounces, p.rr_start, r->long_ray};
+    Params prm{p.seed, p.width, p.height, p.max_bounces, p.rr_start, r->long_ray, r->stack_entries};
     const size_t nb = p.max_bounces + 2;
     HIP_TRY(hipMemsetAsync(P.counts, 0, nb * 4, r->stream));
     HIP_TRY(hipMemsetAsync(P.scounts, 0, nb * 4, r->stream));
@@ -1000,7 +1064,7 @@ int mi355pt_render_step(mi355pt_render* r, uint32_t spp) {
     const size_t npix = (size_t)p.width * p.height, cap = r->P.cap;
     const size_t ppc = std::min(npix, cap);
     const size_t spc = ppc == npix ? std::max<size_t>(1, cap / npix) : 1;
-    const Params kprm{p.seed, p.width, p.height, p.max_bounces, p.rr_start, r->long_ray};
+    const Params kprm{p.seed, p.width, p.height, p.max_bounces, p.rr_start, r->long_ray, r->stack_entries};
     for (size_t pix_base = 0; pix_base < npix; pix_base += ppc) {
         const uint32_t np = (uint32_t)std::min(ppc, npix - pix_base);
         for (uint32_t s0 = 0; s0 < spp; s0 += (uint32_t)spc) {
@@ -1065,7 +1129,7 @@ int mi355pt_trace_primary(mi355pt_render* r, uint32_t x0, uint32_t y0, uint32_t 
     int32_t *dn, *dm, *df; float* dt;
     HIP_TRY(hipMalloc((void**)&dn, n * 4)); HIP_TRY(hipMalloc((void**)&dm, n * 4)); HIP_TRY(hipMalloc((void**)&df, n * 4)); HIP_TRY(hipMalloc((void**)&dt, n * 4));
     const mi355pt_render_params& p = r->prm;
-    Params prm{p.seed, p.width, p.height, p.max_bounces, p.rr_start, r->long_ray};
+    Params prm{p.seed, p.width, p.height, p.max_bounces, p.rr_start, r->long_ray, r->stack_entries};
     if (n > r->P.cap) { (void)hipFree(dn); (void)hipFree(dm); (void)hipFree(df); (void)hipFree(dt); return fail(MI355PT_ERR_TOO_LARGE, "rectangle larger than the path pool"); }
     hipLaunchKernelGGL(k_primary_init, dim3(grid_for(r, n)), dim3(kBlock), 0, r->stream, r->P, prm, x0, y0, rw, rh);
     const int rc = run_paths(r, (uint32_t)n, 0, 1);
@@ -1121,7 +1185,7 @@ int mi355pt_sample_radiance(mi355pt_render* r, const uint32_t* pixel, const uint
     HIP_TRY(hipMalloc((void**)&dl, (size_t)count * 12)); HIP_TRY(hipMalloc((void**)&dm, (size_t)count * 12));
     HIP_TRY(hipMemcpy(dp, pixel, (size_t)count * 4, hipMemcpyHostToDevice)); HIP_TRY(hipMemcpy(ds, sample, (size_t)count * 4, hipMemcpyHostToDevice));
     const mi355pt_render_params& p = r->prm;
-    const Params kprm{p.seed, p.width, p.height, p.max_bounces, p.rr_start, r->long_ray};
+    const Params kprm{p.seed, p.width, p.height, p.max_bounces, p.rr_start, r->long_ray, r->stack_entries};
     hipLaunchKernelGGL(k_init, dim3(grid_for(r, count)), dim3(kBlock), 0, r->stream, r->P, kprm,
                        count, 0u, 1u, (const uint32_t*)r->cnt, 0u, 1u, (const uint32_t*)dp, (const uint32_t*)ds);
     int rc = run_paths(r, count);
@@ -1139,8 +1203,9 @@ int mi355pt_sample_radiance(mi355pt_render* r, const uint32_t* pixel, const uint
 int mi355pt_render_stats(mi355pt_render* r, mi355pt_stats* st) {
     if (!r || !st) return fail(MI355PT_ERR_INVALID, "null argument");
     if (int rc = mi355pt_render_sync(r)) return rc;
-    unsigned long long h[8];
+    unsigned long long h[16];
     HIP_TRY(hipMemcpy(h, r->P.stat, sizeof(h), hipMemcpyDeviceToHost));
+    for (int i = 0; i < 8; i++) st->debug[i] = h[8 + i];
     st->closest_rays = h[0]; st->shadow_rays = h[1]; st->samples = h[2]; st->bvh_node_visits = h[3]; st->bvh_tri_tests = h[4];
     st->shadow_node_visits = h[5]; st->shadow_tri_tests = h[6]; st->max_nodes_per_ray = h[7];
     st->extend_ms = r->ms[0]; st->shade_ms = r->ms[1]; st->connect_ms = r->ms[2]; st->other_ms = r->ms[3];
@@ -1150,7 +1215,7 @@ int mi355pt_render_stats(mi355pt_render* r, mi355pt_stats* st) {
 int mi355pt_render_reset_stats(mi355pt_render* r) {
     if (!r) return fail(MI355PT_ERR_INVALID, "null argument");
     if (int rc = mi355pt_render_sync(r)) return rc;
-    HIP_TRY(hipMemsetAsync(r->P.stat, 0, 8 * sizeof(unsigned long long), r->stream));
+    HIP_TRY(hipMemsetAsync(r->P.stat, 0, 16 * sizeof(unsigned long long), r->stream));
     HIP_TRY(hipStreamSynchronize(r->stream));
     for (double& m : r->ms) m = 0;
     r->extend_launches = 0;

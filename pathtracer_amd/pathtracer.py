@@ -159,7 +159,7 @@ class PathTracer:
     def stats(self):
         st = capi.Stats()
         capi.check(self.lib, self.lib.mi355pt_render_stats(self.h, C.byref(st)), "render_stats")
-        return {k: getattr(st, k) for k, _ in capi.Stats._fields_}
+        return {k: (list(getattr(st, k)) if k == "debug" else getattr(st, k)) for k, _ in capi.Stats._fields_}
 
     def reset_stats(self):
         capi.check(self.lib, self.lib.mi355pt_render_reset_stats(self.h), "reset_stats")
