@@ -306,6 +306,24 @@ void flatten_tree(const MeshTree& t, FlatMesh& out) {
     }
     out.node_words.assign(16 * (size_t)nrec, 0.0f);
     auto put_u = [&](size_t w, uint32_t v) { memcpy(&out.node_words[w], &v, 4); };
+    // A leaf of more than kMaxLeaf triangles becomes a chain of bound-less records (count word kChain):
+    // left = the next kMaxLeaf slots, right = the rest.  The kernels enter a chain record without a slab
+    // test -- the reference tests no bound below an internal node's own (model.cpp:6-25) -- so the set of
+    // triangles tested is unchanged, and every leaf reference the kernels meet holds 1..kMaxLeaf slots.
+    auto leaf_ref = [&](uint32_t first, uint32_t cnt, uint32_t& ref, uint32_t& word) {
+        if (cnt <= kMaxLeaf) { ref = first; word = cnt; return; }
+        const size_t links = (cnt - 1) / kMaxLeaf;               // records in the chain
+        const size_t base = out.node_words.size() / 16;
+        out.node_words.resize(out.node_words.size() + 16 * links, 0.0f);
+        for (size_t l = 0; l < links; l++) {
+            const size_t w = 16 * (base + l);
+            put_u(w + 12, first); put_u(w + 14, kMaxLeaf);
+            first += kMaxLeaf; cnt -= kMaxLeaf;
+            if (l + 1 < links) { put_u(w + 13, (uint32_t)(base + l + 1)); put_u(w + 15, kChain); }
+            else { put_u(w + 13, first); put_u(w + 15, cnt); }
+        }
+        ref = (uint32_t)base; word = kChain;
+    };
     for (size_t n = 0; n < nn; n++) {
         if (rec[n] < 0) continue;
         const TmpNode& s = t.nodes[n];
@@ -315,12 +333,12 @@ void flatten_tree(const MeshTree& t, FlatMesh& out) {
             const TmpNode& cn = t.nodes[ch[c]];
             memcpy(&out.node_words[w + 6 * c], cn.bound, 6 * sizeof(float));
             if (cn.left >= 0) { put_u(w + 12 + c, (uint32_t)rec[ch[c]]); put_u(w + 14 + c, kInternal); }
-            else { put_u(w + 12 + c, first_slot[ch[c]]); put_u(w + 14 + c, cn.end - cn.begin); }
+            else { uint32_t ref, word; leaf_ref(first_slot[ch[c]], cn.end - cn.begin, ref, word); put_u(w + 12 + c, ref); put_u(w + 14 + c, word); }
         }
     }
     const TmpNode& root = t.nodes[0];
     if (root.left >= 0) { out.root_ref = 0; out.root_cnt = kInternal; }
-    else { out.root_ref = first_slot[0]; out.root_cnt = root.end - root.begin; }
+    else leaf_ref(first_slot[0], root.end - root.begin, out.root_ref, out.root_cnt);
 }
 
 }  // namespace ptb

@@ -39,8 +39,10 @@ void export_tree(const MeshTree& t, std::vector<mi355pt_bvh_node>& nodes, std::v
 // Flattened layout.  One 64-byte record per INTERNAL node:
 //   f[0..5]  = left child's bound, f[6..11] = right child's bound,
 //   u[12], u[13] = left/right reference, u[14], u[15] = left/right count.
-//   count == 0xFFFFFFFF : the child is internal, reference = its record index;
-//   otherwise           : the child is a leaf, reference = first triangle slot, count = #triangles.
+//   count == 0xFFFFFFFF (kInternal) : the child is internal, reference = its record index;
+//   count == 0xFFFFFFFE (kChain)    : the child is a chain record (a large leaf cut into pieces of kMaxLeaf
+//                                     slots); reference = its record index; it is entered WITHOUT a slab test;
+//   otherwise                       : the child is a leaf, reference = first triangle slot, count = 0..kMaxLeaf.
 // Triangle slots are laid out in RIGHT-first depth-first order, so that "smaller slot" is exactly
 // the reference's tie-break (right child wins, earlier face in a leaf wins; src/model.cpp:16,36).
 struct FlatMesh {
@@ -49,7 +51,7 @@ struct FlatMesh {
     uint32_t root_ref = 0, root_cnt = 0;
     int      max_depth = 0;
 };
-constexpr uint32_t kInternal = 0xFFFFFFFFu;
+constexpr uint32_t kInternal = 0xFFFFFFFFu, kChain = 0xFFFFFFFEu, kMaxLeaf = 4;
 void flatten_tree(const MeshTree& t, FlatMesh& out);
 
 }  // namespace ptb

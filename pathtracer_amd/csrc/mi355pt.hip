@@ -44,11 +44,10 @@ struct DPaths {
     uint32_t *squeue;     // slots with shadow work this bounce
     uint32_t *counts;     // [b] = #paths entering bounce b (b >= 1)
     uint32_t *scounts;    // [b] = #paths with shadow work at bounce b
-    unsigned long long *coop;  // per resident wave: kCoopCap entries of the shared stack used to finish long rays
     uint32_t *work;       // [b] = next queue index to hand out in k_extend of bounce b (persistent refill)
     unsigned long long *stat;   // [0] closest rays [1] shadow rays [2] samples [3,4] extend node visits / tri tests [5,6] connect ditto
 };
-struct Params { uint32_t seed, width, height, max_bounces, rr_start, long_ray, stack_entries; };
+struct Params { uint32_t seed, width, height, max_bounces, rr_start, stack_entries, node_lanes, owner_lanes; };
 
 #define PT_LD3(arr, cap, i) f3((arr)[(i)], (arr)[(size_t)(cap) + (i)], (arr)[2 * (size_t)(cap) + (i)])
 #define PT_ST3(arr, cap, i, v) do { (arr)[(i)] = (v).x; (arr)[(size_t)(cap) + (i)] = (v).y; (arr)[2 * (size_t)(cap) + (i)] = (v).z; } while (0)
@@ -97,308 +96,318 @@ __global__ void __launch_bounds__(kBlock) k_init(DPaths P, Params prm, uint32_t 
     }
 }
 
+// ---------------------------------------------------------------------- ray generation
+// HaltonSampler::SamplePixel + GenCameraRayContext for every path of the chunk (sampler.cpp:15-32,
+// raytracer.cpp:272-316).  The main ray goes to P.ray so that k_extend reads every bounce the same way;
+// k_shade recomputes the two differential rays for the primary hit only.
+__global__ void __launch_bounds__(kBlock) k_raygen(DCamera cam, DPaths P, Params prm, uint32_t n, uint32_t jitter) {
+    const size_t cap = P.cap;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        Ray r; F3 rd, td;
+        camera_rays(cam, prm.seed, P.pix[i], P.smp[i], prm.width, jitter != 0, r, rd, td);
+        P.ray[i] = r.p.x; P.ray[cap + i] = r.p.y; P.ray[2 * cap + i] = r.p.z;
+        P.ray[3 * cap + i] = r.d.x; P.ray[4 * cap + i] = r.d.y; P.ray[5 * cap + i] = r.d.z;
+    }
+}
+
 // ---------------------------------------------------------------------- extend (closest hit)
-// TraceNode -> Model::IntersectRay -> TraceBVHNode -> IntersectRayWithFace for every queued ray.
-// Persistent waves with per-lane ray refill: path lengths through the BVH are heavy-tailed (a
-// grazing ray crosses hundreds of nodes, its neighbours a dozen), so a lane that finishes its ray
-// pulls the next one from a global counter instead of idling until the slowest lane of its wave
-// is done.  Each lane runs a small state machine (fetch -> next object -> next mesh -> traverse);
-// within a wave, node steps and the (expensive, bit-exact) triangle tests are run in separate
-// phases so that each executes with as many lanes active as possible.
-enum { ST_FETCH = 0, ST_INST, ST_MESH, ST_TRAV, ST_DONE };
-#ifndef PT_POPCULL
-#define PT_POPCULL 0     // re-testing an entry's distance when it is popped saved 1-2 % of node visits and cost a scratch array
-#endif
-#ifndef PT_EXT_WAVES
-#define PT_EXT_WAVES 3
-#endif
-constexpr int kNodeSteps = 4;
-constexpr int kLeafCap = 8;        // parked leaves per lane (LDS)
-constexpr int kTriEnter = 40;      // lanes with parked leaves that start a triangle phase
-constexpr int kTriExit = 16;       // ... and the count below which it yields to node steps again
-constexpr int kNodeMin = 12;       // with fewer lanes able to take a node step, test triangles instead
-// A ray that has taken more than kLongRay node steps in one mesh is finished by its whole wave:
-// the 64 lanes pop 64 entries of a shared (per-wave, global-memory) stack at a time.  This bounds the
-// kernel's tail -- the longest single traversal (thousands of dependent node fetches for a ray that
-// skims the whole grid) would otherwise set the kernel time.  The result is unchanged: it is the
-// minimum over the same triangle set in (t, slot) order, whatever order the entries are visited in.
-constexpr uint32_t kLongRayDefault = 128;     // override: MI355PT_LONG_RAY (0 = every traversal is finished cooperatively)
-constexpr uint32_t kCoopCap = 4096;          // entries of the shared stack per wave
-constexpr uint32_t kCoopStride = kCoopCap + 64;   // slack: the overflow guard may overshoot by a few pushes
-__device__ __forceinline__ unsigned long long coop_load(const unsigned long long* p) {
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // sc1: served by L2, never a stale L1 line
+// TraceNode -> Model::IntersectRay -> TraceBVHNode -> IntersectRayWithFace for every queued ray
+// (raytracer.cpp:189-258, model.cpp:4-247, model.h:227-347).
+//
+// One workgroup = one persistent wave64.  Each lane owns one ray at a time and walks the BVH with a
+// private stack in LDS.  What makes it fast on a 64-wide machine:
+//   * node steps are straight-line code (both child slabs always evaluated, predicated pushes), and the
+//     wave keeps taking node steps only while most of its lanes can take one;
+//   * leaves are not tested where they are found: a (leaf, owner) item goes to a per-wave queue in LDS,
+//     and the queue is drained by the whole wave, one triangle per lane, whatever ray it belongs to
+//     (the ray is read back from LDS, the result merged with a 64-bit LDS atomic min on the owner's
+//     (t, slot) key) -- the expensive bit-exact triangle test always runs with full lanes;
+//   * rays that finish are replaced in batches (setup code runs for many lanes at once), from per-wave
+//     chunks of the global queue (one global atomic per chunk);
+//   * when the global queue is empty, idle lanes steal the bottom entry of a busy lane's stack and walk
+//     that subtree for the same owner: the tail of the kernel (one ray skimming thousands of nodes) is
+//     spread over the wave.
+// None of this changes results: the winner is the minimum over the same triangle set in (t, slot) order
+// (slot order == the reference's tie-break order, bvh_build.h), whoever tested which triangle when.
+enum { LS_IDLE = 0, LS_SETUP, LS_TRAV, LS_WAIT, LS_THIEF, LS_DONE };
+constexpr int kExtBlock = 64;
+constexpr uint32_t kLeafQ = 256;         // leaf items per wave; a node step needs room for 2 x 64
+constexpr uint32_t kNodeLanes = 40;      // the node loop yields when fewer lanes than this can take a step (MI355PT_NODE_LANES)
+constexpr uint32_t kMaxLeaf = ptb::kMaxLeaf;
+constexpr uint32_t kExtendGuard = 1u << 22;
+static_assert(kMaxLeaf == 4, "leaf items carry count-1 in 2 bits and the triangle list holds 64 x 4 entries");
+
+// LDS of one wave, in dwords, after the stack of `E` entries x 64 lanes
+constexpr uint32_t kLdsQRef = 0, kLdsQOwn = kLdsQRef + kLeafQ, kLdsRay = kLdsQOwn + kLeafQ, kLdsKey = kLdsRay + 64 * 8,
+                   kLdsWork = kLdsKey + 64 * 2, kLdsXfer = kLdsWork + 64, kLdsTri = kLdsXfer + 128, kLdsEnd = kLdsTri + 64;
+static_assert((kLdsRay % 4) == 0 && (kLdsKey % 2) == 0, "alignment of the float4 / u64 parts");
+inline size_t extend_lds_bytes(uint32_t entries) { return ((size_t)entries * 64 + kLdsEnd) * 4; }
+
+// (t, slot) as one ordered 64-bit key.  Accepted distances are >= 0 or -0.0 (the reference rejects only t < 0 and
+// compares the two zeros equal): both zeros map to the same high word, the sign is kept in bit 0 so that the
+// winner's t is reported with the reference's bits.
+__device__ __forceinline__ unsigned long long hit_key(float t, uint32_t slot) {
+    const uint32_t tb = __float_as_uint(t);
+    const uint32_t hi = (t == 0.0f) ? 0u : tb;
+    return ((unsigned long long)hi << 32) | (unsigned long long)((slot << 1) | (tb == 0x80000000u ? 1u : 0u));
 }
-__device__ __forceinline__ void coop_store(unsigned long long* p, unsigned long long v) {
-    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ unsigned long long coop_entry(uint32_t ref, float tnear) { return ((unsigned long long)__float_as_uint(tnear) << 32) | ref; }
-__device__ __forceinline__ F3 shfl3(F3 v, int j) { return f3(__shfl(v.x, j), __shfl(v.y, j), __shfl(v.z, j)); }
+__device__ __forceinline__ float key_dist(unsigned long long k) { return (k & 1ull) ? -0.0f : __uint_as_float((uint32_t)(k >> 32)); }
 
 template <bool COUNT>
-__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PT_EXT_WAVES, 8))) k_extend(DScene S, DCamera cam, DPaths P, Params prm, uint32_t bounce, uint32_t n0, uint32_t jitter) {
+__global__ void __launch_bounds__(kExtBlock) k_extend(DScene S, DPaths P, Params prm, uint32_t bounce, uint32_t n0) {
     const uint32_t n = bounce == 0 ? n0 : P.counts[bounce];
     const uint32_t* q = bounce == 0 ? nullptr : P.queue[bounce & 1];
     uint32_t* work = &P.work[bounce];
     const size_t cap = P.cap;
+    extern __shared__ uint32_t sm[];
+    const uint32_t lane = threadIdx.x;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    uint32_t* stk = sm;                                          // [E][64]
+    uint32_t* aux = sm + prm.stack_entries * 64;
+    uint32_t* qref = aux + kLdsQRef; uint32_t* qown = aux + kLdsQOwn;
+    float4* rayl = (float4*)(aux + kLdsRay);                     // [64][2]: (o, -), (d, -) of the owner's ray in mesh space
+    unsigned long long* keyl = (unsigned long long*)(aux + kLdsKey);   // [64] best (t, slot) of the owner's current mesh
+    uint32_t* nwork = aux + kLdsWork;                            // [64] lanes still walking for this owner
+    uint32_t* xfer = aux + kLdsXfer;                             // [128] steal hand-over
+    uint8_t* tril = (uint8_t*)(aux + kLdsTri);                   // [256] expanded triangle list of one drain round
+#define PT_STK(i) stk[(i) * 64 + lane]
     WorkCounters wc; wc.nodes = 0; wc.tris = 0;
-    extern __shared__ uint32_t sm_stack[];       // stack_entries x kBlock dwords, sized by the host from the tree depth
-#define PT_STK(i) sm_stack[(i) * kBlock + threadIdx.x]
-#if PT_POPCULL
-#define PT_ST(i, v) stack_t[i] = (v)
-#define PT_GT(i) stack_t[i]
-#else
-#define PT_ST(i, v) do {} while (0)
-#define PT_GT(i) (-kBig)
-#endif
-#define PT_LSTK(i) sm_stack[(prm.stack_entries + (i)) * kBlock + threadIdx.x]
-#if PT_POPCULL
-    float stack_t[kStackSize];
-#endif
-    const int lane = __lane_id();
-    int state = ST_FETCH, ii = 0, mi = 0, sp = 0, ls = 0;
-    uint32_t slot = 0, lf = 0, lc = 0, bslot = 0;
-    float bt = 0.0f, pabs = 0.0f;
-    bool changed = false;
-    Ray wr, lr; wr.p = wr.d = lr.p = lr.d = f3(0, 0, 0);
-    F3 inv = f3(0, 0, 0);
-    HitRec best; best.t = kBig; best.inst = -1; best.mesh = -1; best.slot = 0;
-    uint32_t ray_nodes = 0, steps = 0;
-    // queue chunk per atomic: large while there is plenty of work per wave, 64 when the queue is short
-    const uint32_t nwaves = gridDim.x * (kBlock / 64);
+    uint32_t state = LS_IDLE, slot = 0, ii = 0, mi = 0, sp = 0, sb = 0, owner = lane;
+    F3 o = f3(0, 0, 0), inv = f3(0, 0, 0);
+    float bt = kBig, pabs = 0.0f;
+    float best_t = kBig; int best_inst = -1, best_mesh = -1; uint32_t best_slot = 0;
+    uint32_t qh = 0, nq = 0;                                     // leaf queue (ring): head, count -- wave-uniform
+    const uint32_t nwaves = gridDim.x;
     uint32_t chunk = (n / (8u * nwaves)) & ~63u; chunk = chunk < 64u ? 64u : (chunk > 1024u ? 1024u : chunk);
     uint32_t pool_next = 0, pool_end = 0; bool exhausted = false;
-    unsigned long long* coop = P.coop + (size_t)(blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6)) * kCoopStride;
-    unsigned long long dbg_outer = 0, dbg_node_it = 0, dbg_node_act = 0, dbg_tri_it = 0, dbg_tri_act = 0, dbg_coop = 0;
-    unsigned long long clk_node = 0, clk_load = 0, clk_tri = 0; const unsigned long long clk_begin = COUNT ? clock64() : 0;
+    uint32_t guard = 0;
+
     for (;;) {
-        if (COUNT) dbg_outer++;
-        // ---- refill idle lanes from the wave's chunk of the queue; one atomic on the global counter per chunk
-        // (a per-refill atomic made every wave of the chip serialise on one L2 address)
-        const unsigned long long need = __ballot(state == ST_FETCH);
-        if (need) {
-            if (pool_next >= pool_end && !exhausted) {
-                uint32_t base = 0;
-                if (lane == 0) base = atomicAdd(work, chunk);
-                base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-                if (base >= n) { exhausted = true; pool_next = pool_end = n; }
-                else { pool_next = base; pool_end = base + chunk < n ? base + chunk : n; }
+        // every pass makes progress (a node step, a drained queue, a finished mesh or a new ray), so a wave needs a few
+        // thousand passes; the guard turns a scheduling bug into an error code (stat[15]) instead of a hung GPU
+        if (++guard > kExtendGuard) { if (lane == 0) atomicOr(&P.stat[15], 1ull); break; }
+        // ================= setup: new rays for idle lanes, next object / mesh for lanes between meshes
+        {
+            Ray wr; wr.p = wr.d = f3(0, 0, 0);
+            if (state == LS_SETUP) {
+                wr.p = f3(P.ray[slot], P.ray[cap + slot], P.ray[2 * cap + slot]);
+                wr.d = f3(P.ray[3 * cap + slot], P.ray[4 * cap + slot], P.ray[5 * cap + slot]);
             }
-            if (state == ST_FETCH) {
-                const uint32_t idx = pool_next + (uint32_t)__popcll(need & ((1ull << lane) - 1ull));
-                if (idx < pool_end) {
-                    slot = q ? q[idx] : idx;
-                    if (bounce == 0 && jitter != 2) { F3 rd, td; camera_rays(cam, prm.seed, P.pix[slot], P.smp[slot], prm.width, jitter != 0, wr, rd, td); }
-                    else { wr.p = f3(P.ray[slot], P.ray[cap + slot], P.ray[2 * cap + slot]);
-                           wr.d = f3(P.ray[3 * cap + slot], P.ray[4 * cap + slot], P.ray[5 * cap + slot]); }
-                    best.t = kBig; best.inst = -1; best.mesh = -1; best.slot = 0;
-                    ii = 0; state = ST_INST;
-                    if (COUNT) ray_nodes = 0;
-                } else if (exhausted) state = ST_DONE;      // otherwise: wait for the next chunk
-            }
-            const uint32_t took = (uint32_t)__popcll(need);
-            pool_next = pool_end - pool_next < took ? pool_end : pool_next + took;
-        }
-        if (__ballot(state != ST_DONE) == 0) break;
-        // ---- next object of the scene graph (TraceNode, raytracer.cpp:189-258: earlier object wins ties)
-        if (state == ST_INST) {
-            if (ii >= S.num_insts) {
-                P.ht[slot] = best.t; P.hinst[slot] = best.inst; P.hmesh[slot] = best.mesh; P.hslot[slot] = best.slot;
-                state = ST_FETCH;
-                if (COUNT) atomicMax(&P.stat[7], (unsigned long long)ray_nodes);
-            } else {
-                const DInst& in = S.insts[ii];
-                lr = to_inst(S, in, wr);
-                if (in.kind == MI355PT_OBJ_PLANE) {
-                    float t; bool front; F3 Pp;
-                    if (plane_hit(lr.p, lr.d, SIDE_BOTH, t, front, Pp) && t < best.t) { best.t = t; best.inst = ii; best.mesh = -1; best.slot = 0; }
-                    ii++;
-                } else if (in.kind == MI355PT_OBJ_MODEL) {
-                    inv = f3(1.0f, 1.0f, 1.0f) / lr.d;
-                    pabs = prune_abs(lr.p);
-                    float tn;
-                    if (!slab(S.models[in.model].aabb, lr.p, inv, tn)) ii++;       // Model::IntersectRay, model.cpp:212
-                    else { mi = 0; state = ST_MESH; }
-                } else ii++;
-            }
-        }
-        // ---- next mesh of the model (model.cpp:223-245)
-        if (state == ST_MESH) {
-            const DModel& mo = S.models[S.insts[ii].model];
-            if (mi >= mo.num_meshes) { ii++; state = ST_INST; }
-            else {
-                const DMesh& M = S.meshes[mo.first_mesh + mi];
-                float tn;
-                if (!slab(M.aabb, lr.p, inv, tn)) mi++;
-                else {
-                    // start from the global best with bslot = 0: an equal-t candidate of a later mesh / object loses
-                    bt = best.t; bslot = 0; changed = false; sp = 0; lc = 0; ls = 0; steps = 0;
-                    if (M.root_cnt == 0xFFFFFFFFu) {
-                        if (COUNT) wc.nodes++;
-                        if (!slab(M.root_bound, lr.p, inv, tn)) mi++;
-                        else { PT_STK(0) = M.root_ref; PT_ST(0, -kBig); sp = 1; state = ST_TRAV; }
+            for (;;) {
+                if (state == LS_IDLE && lane >= prm.owner_lanes) state = LS_DONE;     // test knob: these lanes only ever steal
+                const unsigned long long need = __ballot(state == LS_IDLE);
+                if (need) {
+                    if (pool_next >= pool_end && !exhausted) {       // one atomic on the global counter per chunk
+                        uint32_t base = 0;
+                        if (lane == 0) base = atomicAdd(work, chunk);
+                        base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+                        if (base >= n) { exhausted = true; pool_next = pool_end = n; }
+                        else { pool_next = base; pool_end = base + chunk < n ? base + chunk : n; }
+                    }
+                    if (state == LS_IDLE) {
+                        const uint32_t idx = pool_next + (uint32_t)__popcll(need & lt);
+                        if (idx < pool_end) {
+                            slot = q ? q[idx] : idx;
+                            wr.p = f3(P.ray[slot], P.ray[cap + slot], P.ray[2 * cap + slot]);
+                            wr.d = f3(P.ray[3 * cap + slot], P.ray[4 * cap + slot], P.ray[5 * cap + slot]);
+                            best_t = kBig; best_inst = -1; best_mesh = -1; best_slot = 0;
+                            ii = 0; mi = 0; state = LS_SETUP;
+                        } else if (exhausted) state = LS_DONE;
+                    }
+                    const uint32_t took = (uint32_t)__popcll(need);
+                    pool_next = pool_end - pool_next < took ? pool_end : pool_next + took;
+                }
+                if (__ballot(state == LS_SETUP || state == LS_IDLE) == 0) break;
+                // ---- one step of TraceNode's walk over the objects (earlier object wins ties, raytracer.cpp:208,238)
+                uint32_t root_leaf = 0;                               // leaf item to enqueue when a mesh's root is a leaf
+                if (state == LS_SETUP) {
+                    if (ii >= (uint32_t)S.num_insts) {
+                        P.ht[slot] = best_t; P.hinst[slot] = best_inst; P.hmesh[slot] = best_mesh; P.hslot[slot] = best_slot;
+                        state = LS_IDLE;
                     } else {
-                        uint32_t first = M.root_ref, cnt = M.root_cnt;
-                        while (cnt) { const uint32_t c = cnt > 15u ? 15u : cnt; if (sp < kStackSize) { PT_STK(sp) = kLeafFlag | (c << 27) | first; sp++; } first += c; cnt -= c; }
-                        state = ST_TRAV;
+                        const DInst& in = S.insts[ii];
+                        const Ray lr = to_inst(S, in, wr);
+                        if (in.kind == MI355PT_OBJ_PLANE) {
+                            float t; bool front; F3 Pp;
+                            if (plane_hit(lr.p, lr.d, SIDE_BOTH, t, front, Pp) && t < best_t) { best_t = t; best_inst = (int)ii; best_mesh = -1; best_slot = 0; }
+                            ii++;
+                        } else if (in.kind == MI355PT_OBJ_MODEL) {
+                            const DModel& mo = S.models[in.model];
+                            const F3 linv = f3(1.0f, 1.0f, 1.0f) / lr.d;
+                            float tn;
+                            if (mi >= (uint32_t)mo.num_meshes || (mi == 0 && !slab(mo.aabb, lr.p, linv, tn))) { ii++; mi = 0; }   // model.cpp:212
+                            else {
+                                const DMesh& M = S.meshes[mo.first_mesh + mi];                                        // model.cpp:223-245
+                                bool go = slab(M.aabb, lr.p, linv, tn);
+                                if (go && M.root_cnt == kInternal) { if (COUNT) wc.nodes++; go = slab(M.root_bound, lr.p, linv, tn); }
+                                if (go && M.root_cnt == 0u) go = false;
+                                if (!go) mi++;
+                                else {
+                                    // the mesh starts from the best so far with slot key 0: an equal-t candidate of a later
+                                    // mesh / object loses (model.cpp:237), only a strictly closer one replaces it
+                                    rayl[2 * lane] = make_float4(lr.p.x, lr.p.y, lr.p.z, 0.0f);
+                                    rayl[2 * lane + 1] = make_float4(lr.d.x, lr.d.y, lr.d.z, 0.0f);
+                                    keyl[lane] = hit_key(best_t, 0u) & ~1ull;
+                                    owner = lane; sb = 0;
+                                    if (M.root_cnt >= kChain) {
+                                        o = lr.p; inv = linv; pabs = prune_abs(lr.p); bt = best_t;
+                                        PT_STK(0) = M.root_ref; sp = 1; nwork[lane] = 1; state = LS_TRAV;
+                                    } else {
+                                        root_leaf = kLeafFlag | ((M.root_cnt - 1u) << 27) | M.root_ref;
+                                        sp = 0; nwork[lane] = 0; state = LS_WAIT;
+                                    }
+                                }
+                            }
+                        } else ii++;
                     }
                 }
+                const unsigned long long rl = __ballot(root_leaf != 0u);
+                if (rl) {                                             // at most one per lane per setup phase, the queue was empty
+                    if (root_leaf) { const uint32_t pos = (qh + nq + (uint32_t)__popcll(rl & lt)) % kLeafQ; qref[pos] = root_leaf; qown[pos] = lane; }
+                    nq += (uint32_t)__popcll(rl);
+                }
             }
         }
-        // ---- cooperative finish of long rays (see kLongRay)
-        unsigned long long longmask = __ballot(state == ST_TRAV && steps >= prm.long_ray);
-        while (longmask) {
-            const int j = __ffsll((long long)longmask) - 1;
-            longmask &= longmask - 1;
-            const F3 co = shfl3(lr.p, j), cd = shfl3(lr.d, j), cinv = shfl3(inv, j);
-            const float cpabs = prune_abs(co);
-            float gbt = __shfl(bt, j); uint32_t gslot = __shfl(bslot, j);
-            bool gchanged = false;
-            uint32_t sc = 0;
-            if (lane == j) {                                  // lane j hands its private stack (and pending leaf) over
-                for (int k = 0; k < sp; k++) coop_store(&coop[k], coop_entry(PT_STK(k), PT_GT(k)));
-                sc = (uint32_t)sp;
-                if (lc > 0) { coop_store(&coop[sc], coop_entry(kLeafFlag | (lc << 27) | lf, -kBig)); sc++; }
-                for (int k = 0; k < ls; k++) { coop_store(&coop[sc], coop_entry(PT_LSTK(k), -kBig)); sc++; }
-                sp = 0; lc = 0; ls = 0; steps = 0;
+        if (__ballot(state != LS_DONE) == 0) break;
+        __syncthreads();
+        // ================= node steps, while most lanes can take one
+        {
+            const uint32_t ntrav = (uint32_t)__popcll(__ballot(state == LS_TRAV || state == LS_THIEF));
+            uint32_t th = (3u * ntrav + 3u) / 4u; th = th > prm.node_lanes ? prm.node_lanes : th;
+            bool first = true;
+            for (;;) {
+                const bool want = (state == LS_TRAV || state == LS_THIEF) && sp > sb;
+                const uint32_t nw = (uint32_t)__popcll(__ballot(want));
+                if (nw == 0 || (!first && nw < th) || kLeafQ - nq < 128u) break;
+                first = false;
+                uint32_t leafL = 0, leafR = 0;
+                if (want) {
+                    sp--;
+                    const uint32_t e = PT_STK(sp);
+                    const float4* np = S.bvh_nodes + 4 * (size_t)e;
+                    const float4 w0 = np[0], w1 = np[1], w2 = np[2], w3 = np[3];
+                    if (COUNT) wc.nodes++;
+                    const uint32_t lref = __float_as_uint(w3.x), rref = __float_as_uint(w3.y), lcnt = __float_as_uint(w3.z), rcnt = __float_as_uint(w3.w);
+                    // both child slabs, always (bvh.h:88-129 with 1/dir hoisted; same values)
+                    const bool s0 = inv.x < 0, s1 = inv.y < 0, s2 = inv.z < 0;
+                    float tl, tr; bool hl, hr;
+                    {
+                        float tmin = ((s0 ? w0.w : w0.x) - o.x) * inv.x, tmax = ((s0 ? w0.x : w0.w) - o.x) * inv.x;
+                        const float tymin = ((s1 ? w1.x : w0.y) - o.y) * inv.y, tymax = ((s1 ? w0.y : w1.x) - o.y) * inv.y;
+                        bool ok = !((tmin > tymax) || (tymin > tmax));
+                        if (tymin > tmin) tmin = tymin;
+                        if (tymax < tmax) tmax = tymax;
+                        const float tzmin = ((s2 ? w1.y : w0.z) - o.z) * inv.z, tzmax = ((s2 ? w0.z : w1.y) - o.z) * inv.z;
+                        ok = ok && !((tmin > tzmax) || (tzmin > tmax));
+                        if (tzmin > tmin) tmin = tzmin;
+                        hl = ok; tl = tmin;
+                    }
+                    {
+                        float tmin = ((s0 ? w2.y : w1.z) - o.x) * inv.x, tmax = ((s0 ? w1.z : w2.y) - o.x) * inv.x;
+                        const float tymin = ((s1 ? w2.z : w1.w) - o.y) * inv.y, tymax = ((s1 ? w1.w : w2.z) - o.y) * inv.y;
+                        bool ok = !((tmin > tymax) || (tymin > tmax));
+                        if (tymin > tmin) tmin = tymin;
+                        if (tymax < tmax) tmax = tymax;
+                        const float tzmin = ((s2 ? w2.w : w2.x) - o.z) * inv.z, tzmax = ((s2 ? w2.x : w2.w) - o.z) * inv.z;
+                        ok = ok && !((tmin > tzmax) || (tzmin > tmax));
+                        if (tzmin > tmin) tmin = tzmin;
+                        hr = ok; tr = tmin;
+                    }
+                    const float lim = bt * 1.0001f + pabs;              // beyond(): conservative distance cull, pt_device.h
+                    const bool farL = hl & (tl > lim), farR = hr & (tr > lim);
+                    // internal children: entered iff their slab is hit (and not culled); chain records always
+                    const bool pushL = (lcnt == kChain) | ((lcnt == kInternal) & hl & !farL);
+                    const bool pushR = (rcnt == kChain) | ((rcnt == kInternal) & hr & !farR);
+                    // leaf children: the reference tests no leaf bound (model.cpp:6-25), so a leaf whose slab is MISSED is
+                    // still tested; one whose slab is hit beyond the current best is culled like an internal child
+                    if ((lcnt - 1u < kMaxLeaf) & !farL) leafL = kLeafFlag | ((lcnt - 1u) << 27) | lref;
+                    if ((rcnt - 1u < kMaxLeaf) & !farR) leafR = kLeafFlag | ((rcnt - 1u) << 27) | rref;
+                    // near child on top
+                    const bool rnear = pushL & pushR & (tr < tl);
+                    const uint32_t e0 = pushL ? (rnear ? lref : (pushR ? rref : lref)) : rref;    // deeper entry (far child, or the only one)
+                    const uint32_t e1 = rnear ? rref : lref;                                      // top entry when both are pushed
+                    if (pushL | pushR) PT_STK(sp) = e0;
+                    if (pushL & pushR) PT_STK(sp + 1) = e1;
+                    sp += (pushL ? 1u : 0u) + (pushR ? 1u : 0u);
+                }
+                const unsigned long long mL = __ballot(leafL != 0u), mR = __ballot(leafR != 0u);
+                if (mL | mR) {
+                    const uint32_t cL = (uint32_t)__popcll(mL);
+                    if (leafL) { const uint32_t pos = (qh + nq + (uint32_t)__popcll(mL & lt)) % kLeafQ; qref[pos] = leafL; qown[pos] = owner; }
+                    if (leafR) { const uint32_t pos = (qh + nq + cL + (uint32_t)__popcll(mR & lt)) % kLeafQ; qref[pos] = leafR; qown[pos] = owner; }
+                    nq += cL + (uint32_t)__popcll(mR);
+                }
+                if (want && sp == sb) {                               // this lane's share of the ray is walked
+                    atomicSub(&nwork[owner], 1u);
+                    state = state == LS_TRAV ? LS_WAIT : LS_DONE;
+                }
             }
-            sc = __shfl(sc, j);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            while (sc > 0) {
-                if (COUNT) dbg_coop++;
-                uint32_t m = sc < 64u ? sc : 64u;
-                if (kCoopCap - sc < 4u * 64u) { const uint32_t room = (kCoopCap - sc) / 4u; m = room < m ? (room ? room : 1u) : m; }
-                const bool has = (uint32_t)lane < m;
-                unsigned long long e = 0;
-                if (has) e = coop_load(&coop[sc - 1 - (uint32_t)lane]);
-                sc -= m;
-                float mbt = gbt; uint32_t mslot = gslot;
-                unsigned long long pv[4]; int np = 0;
-                if (has) {
-                    const uint32_t ref = (uint32_t)e; const float tn = __uint_as_float((uint32_t)(e >> 32));
-                    if (ref & kLeafFlag) {
-                        const uint32_t first = ref & kLeafSlotMask, cnt = (ref >> 27) & 15u;
-                        for (uint32_t k = 0; k < cnt; k++) { const Tri T = load_tri(S.tris, first + k); if (COUNT) wc.tris++; tri_closest(T, co, cd, SIDE_BOTH, first + k, mbt, mslot); }
-                    } else if (!beyond(tn, mbt, cpabs)) {
-                        const float4* np4 = S.bvh_nodes + 4 * (size_t)ref;
-                        const float4 w0 = np4[0], w1 = np4[1], w2 = np4[2], w3 = np4[3];
-                        if (COUNT) { wc.nodes++; }
-                        const float lb[6] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y};
-                        const float rb[6] = {w1.z, w1.w, w2.x, w2.y, w2.z, w2.w};
-                        const uint32_t cref[2] = {__float_as_uint(w3.x), __float_as_uint(w3.y)}, ccnt[2] = {__float_as_uint(w3.z), __float_as_uint(w3.w)};
-                        for (int c = 0; c < 2; c++) {
-                            if (ccnt[c] == 0xFFFFFFFFu) { float tc; if (slab(c ? rb : lb, co, cinv, tc) && !beyond(tc, mbt, cpabs)) pv[np++] = coop_entry(cref[c], tc); }
-                            else if (ccnt[c] <= 15u) { if (ccnt[c]) pv[np++] = coop_entry(kLeafFlag | (ccnt[c] << 27) | cref[c], -kBig); }
-                            else for (uint32_t k = 0; k < ccnt[c]; k++) { const Tri T = load_tri(S.tris, cref[c] + k); if (COUNT) wc.tris++; tri_closest(T, co, cd, SIDE_BOTH, cref[c] + k, mbt, mslot); }
-                        }
+        }
+        __syncthreads();
+        // ================= drain the leaf queue: one triangle per lane per pass, whatever ray it belongs to
+        while (nq > 0) {
+            const uint32_t m = nq < 64u ? nq : 64u;
+            const bool has = lane < m;
+            const uint32_t myref = has ? qref[(qh + lane) % kLeafQ] : 0u;
+            const uint32_t c1 = has ? (myref >> 27) & 3u : 0u;          // triangles in my item - 1
+            const unsigned long long b0 = __ballot((c1 & 1u) != 0u), b1 = __ballot((c1 & 2u) != 0u);
+            const uint32_t pre = (uint32_t)__popcll(b0 & lt) + 2u * (uint32_t)__popcll(b1 & lt) + lane;
+            const uint32_t total = (uint32_t)__popcll(b0) + 2u * (uint32_t)__popcll(b1) + m;
+            if (has) for (uint32_t k = 0; k <= c1; k++) tril[pre + k] = (uint8_t)((lane << 2) | k);
+            __syncthreads();
+            for (uint32_t base = 0; base < total; base += 64u) {
+                const uint32_t idx = base + lane;
+                if (idx < total) {
+                    const uint32_t code = tril[idx];
+                    const uint32_t pos = (qh + (code >> 2)) % kLeafQ;
+                    const uint32_t tslot = (qref[pos] & kLeafSlotMask) + (code & 3u);
+                    const uint32_t own = qown[pos];
+                    const float4 ro = rayl[2 * own], rd = rayl[2 * own + 1];
+                    const unsigned long long cur = keyl[own];
+                    const Tri T = load_tri(S.tris, tslot);
+                    if (COUNT) wc.tris++;
+                    unsigned long long ck;
+                    if (tri_closest_key(T, f3(ro.x, ro.y, ro.z), f3(rd.x, rd.y, rd.z), tslot, cur, ck)) atomicMin(&keyl[own], ck);
+                }
+            }
+            __syncthreads();
+            qh = (qh + m) % kLeafQ; nq -= m;
+        }
+        // ================= after the drain: refresh pruning distances, finish meshes, steal
+        if (state == LS_TRAV || state == LS_THIEF) bt = __uint_as_float((uint32_t)(keyl[owner] >> 32));
+        if (state == LS_WAIT && nwork[lane] == 0u) {                    // every lane that walked for this ray is done, the queue is empty
+            const unsigned long long k = keyl[lane];
+            if (k != (hit_key(best_t, 0u) & ~1ull)) { best_t = key_dist(k); best_inst = (int)ii; best_mesh = (int)mi; best_slot = (uint32_t)(k & 0xFFFFFFFFull) >> 1; }
+            mi++; state = LS_SETUP;
+        }
+        if (exhausted || prm.owner_lanes < 64u) {
+            const unsigned long long idle = __ballot(state == LS_DONE);
+            const bool can_give = (state == LS_TRAV || state == LS_THIEF) && sp - sb >= 2u;
+            const unsigned long long donors = __ballot(can_give);
+            const uint32_t ni = (uint32_t)__popcll(idle), nd = (uint32_t)__popcll(donors);
+            const uint32_t k = ni < nd ? ni : nd;
+            if (k) {
+                if (can_give) {
+                    const uint32_t r = (uint32_t)__popcll(donors & lt);
+                    if (r < k) { xfer[r] = PT_STK(sb); xfer[64 + r] = owner; sb++; atomicAdd(&nwork[owner], 1u); }
+                }
+                __syncthreads();
+                if (state == LS_DONE) {
+                    const uint32_t r = (uint32_t)__popcll(idle & lt);
+                    if (r < k) {
+                        owner = xfer[64 + r];
+                        const float4 ro = rayl[2 * owner], rd = rayl[2 * owner + 1];
+                        o = f3(ro.x, ro.y, ro.z); inv = f3(1.0f, 1.0f, 1.0f) / f3(rd.x, rd.y, rd.z); pabs = prune_abs(o);
+                        bt = __uint_as_float((uint32_t)(keyl[owner] >> 32));
+                        PT_STK(0) = xfer[r]; sp = 1; sb = 0; state = LS_THIEF;
                     }
                 }
-                // wave minimum in (t, slot) order.  Accepted distances are >= 0 or -0.0 (the reference's `t < 0`
-                // rejects neither zero, and compares them equal): order by the float bits with both zeros mapped
-                // to one key, then take the winner's actual value so that a -0.0 is reported as the reference would.
-                const unsigned long long lkey = ((unsigned long long)(mbt == 0.0f ? 0u : __float_as_uint(mbt)) << 32) | mslot;
-                unsigned long long key = lkey;
-                for (int o = 32; o > 0; o >>= 1) { const unsigned long long other = __shfl_xor(key, o); key = other < key ? other : key; }
-                const unsigned long long prev = ((unsigned long long)(gbt == 0.0f ? 0u : __float_as_uint(gbt)) << 32) | gslot;
-                if (key != prev) {
-                    const int winner = __ffsll((long long)__ballot(lkey == key)) - 1;
-                    gbt = __shfl(mbt, winner); gslot = __shfl(mslot, winner); gchanged = true;
-                }
-                for (int k = 0; k < 4; k++) {
-                    const unsigned long long pm = __ballot(np > k);
-                    if (np > k) coop_store(&coop[sc + (uint32_t)__popcll(pm & ((1ull << lane) - 1ull))], pv[k]);
-                    sc += (uint32_t)__popcll(pm);
-                }
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
             }
-            if (lane == j && gchanged) { bt = gbt; bslot = gslot; changed = true; }
-        }
-        // ---- phase choice.  Popped leaves are parked on a small per-lane leaf stack instead of being tested at
-        // once: triangle tests (3 x 16-B loads + the reference's full 3x3 inverse) are the expensive part, and
-        // testing them the moment one lane reaches a leaf ran that code with ~7 of 64 lanes active.  The
-        // triangle phase runs when enough lanes have parked leaves, or when nobody can take a node step.
-        const unsigned long long tri_m = __ballot(state == ST_TRAV && (lc > 0 || ls > 0));
-        const unsigned long long node_m = __ballot(state == ST_TRAV && lc == 0 && (sp > 0 ? ls + 2 <= kLeafCap : ls == 0));
-        const int ntri = __popcll(tri_m), nnode = __popcll(node_m);
-        const bool tri_phase = ntri > 0 && (ntri >= kTriEnter || nnode < kNodeMin);
-        const unsigned long long clk_p0 = COUNT ? clock64() : 0;
-        if (!tri_phase) {
-        // ---- node phase: up to kNodeSteps pops / visits per lane
-        for (int it = 0; it < kNodeSteps; it++) {
-            const bool want = state == ST_TRAV && lc == 0 && (sp > 0 ? ls + 2 <= kLeafCap : ls == 0);
-            if (__ballot(want) == 0) break;
-            if (COUNT) { dbg_node_it++; dbg_node_act += (unsigned long long)__popcll(__ballot(want)); }
-            if (!want) continue;
-            if (sp == 0) {                                  // this mesh is finished
-                if (changed) { best.t = bt; best.inst = ii; best.mesh = mi; best.slot = bslot; }
-                mi++; state = ST_MESH;
-                continue;
-            }
-            sp--;
-            const uint32_t e = PT_STK(sp);
-            if (e & kLeafFlag) { lf = e & kLeafSlotMask; lc = (e >> 27) & 15u; continue; }     // overflow path of the leaf stack
-            const float4* np = S.bvh_nodes + 4 * (size_t)e;
-            const unsigned long long clk_l0 = COUNT ? clock64() : 0;
-            const float4 w0 = np[0], w1 = np[1], w2 = np[2], w3 = np[3];
-            if (COUNT) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); clk_load += clock64() - clk_l0; }
-#if PT_POPCULL
-            if (beyond(stack_t[sp], bt, pabs)) continue;    // pruned by a hit found since the push
-#endif
-            if (COUNT) { wc.nodes++; ray_nodes++; }
-            steps++;
-            const float lb[6] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y};
-            const float rb[6] = {w1.z, w1.w, w2.x, w2.y, w2.z, w2.w};
-            const uint32_t lref = __float_as_uint(w3.x), rref = __float_as_uint(w3.y), lcnt = __float_as_uint(w3.z), rcnt = __float_as_uint(w3.w);
-            float tl = -kBig, tr = -kBig;
-            bool hl = false, hr = false;
-            if (lcnt == 0xFFFFFFFFu) { hl = slab(lb, lr.p, inv, tl); if (beyond(tl, bt, pabs)) hl = false; }
-            if (rcnt == 0xFFFFFFFFu) { hr = slab(rb, lr.p, inv, tr); if (beyond(tr, bt, pabs)) hr = false; }
-            const bool left_first = !(tr < tl);
-            if (hl && hr) {
-                if (sp + 2 <= kStackSize) {
-                    if (left_first) { PT_STK(sp) = rref; PT_ST(sp, tr); sp++; PT_STK(sp) = lref; PT_ST(sp, tl); sp++; }
-                    else { PT_STK(sp) = lref; PT_ST(sp, tl); sp++; PT_STK(sp) = rref; PT_ST(sp, tr); sp++; }
-                }
-            } else if (hl) { if (sp < kStackSize) { PT_STK(sp) = lref; PT_ST(sp, tl); sp++; } }
-            else if (hr) { if (sp < kStackSize) { PT_STK(sp) = rref; PT_ST(sp, tr); sp++; } }
-            // Leaf children are parked (the reference never tests a leaf's bound, model.cpp:6-25, so neither do we);
-            // a leaf of more than 15 triangles is split, the pieces beyond the leaf stack go on the node stack.
-            for (int c = 0; c < 2; c++) {
-                uint32_t first = c ? rref : lref, cnt = c ? rcnt : lcnt;
-                if (cnt == 0xFFFFFFFFu) continue;
-                while (cnt) {
-                    const uint32_t k = cnt > 15u ? 15u : cnt;
-                    const uint32_t ent = kLeafFlag | (k << 27) | first;
-                    if (ls < kLeafCap) { PT_LSTK(ls) = ent; ls++; }
-                    else if (sp < kStackSize) { PT_STK(sp) = ent; sp++; }
-                    first += k; cnt -= k;
-                }
-            }
-        }
-        if (COUNT) clk_node += clock64() - clk_p0;
-        } else {
-        // ---- triangle phase: every lane with a pending or parked leaf tests one triangle per pass
-        for (;;) {
-            if (lc == 0 && ls > 0 && state == ST_TRAV) { ls--; const uint32_t e = PT_LSTK(ls); lf = e & kLeafSlotMask; lc = (e >> 27) & 15u; }
-            const bool act = state == ST_TRAV && lc > 0;
-            const int nact = __popcll(__ballot(act));
-            if (nact == 0 || (nact < kTriExit && nnode >= kNodeMin)) break;
-            if (COUNT) { dbg_tri_it++; dbg_tri_act += (unsigned long long)nact; }
-            if (act) {
-                const Tri T = load_tri(S.tris, lf);
-                if (COUNT) wc.tris++;
-                changed |= tri_closest(T, lr.p, lr.d, SIDE_BOTH, lf, bt, bslot);
-                lf++; lc--;
-            }
-        }
-        if (COUNT) clk_tri += clock64() - clk_p0;
         }
     }
 #undef PT_STK
-#undef PT_LSTK
-    if (COUNT) { wave_add64(wc.nodes, &P.stat[3]); wave_add64(wc.tris, &P.stat[4]);
-        if (lane == 0) { atomicAdd(&P.stat[8], dbg_outer); atomicAdd(&P.stat[9], dbg_node_it); atomicAdd(&P.stat[10], dbg_node_act);
-                         atomicAdd(&P.stat[11], dbg_tri_it); atomicAdd(&P.stat[12], dbg_tri_act); atomicAdd(&P.stat[13], clk_load);
-                         atomicAdd(&P.stat[14], clk_node); atomicAdd(&P.stat[15], clk_tri); atomicAdd(&P.stat[8], (clock64() - clk_begin) << 32); } }
+    if (COUNT) { wave_add64(wc.nodes, &P.stat[3]); wave_add64(wc.tris, &P.stat[4]); }
 }
 
 // ---------------------------------------------------------------------- shade
@@ -695,7 +704,7 @@ struct mi355pt_render {
     struct Ev { hipEvent_t a, b; int kind; };
     std::vector<Ev> events;
     double ms[4] = {0, 0, 0, 0}; uint64_t extend_launches = 0;
-    int grid = 2048, extend_grid = 768; size_t extend_lds = 0; uint32_t long_ray = kLongRayDefault, stack_entries = 8;
+    int grid = 2048, extend_grid = 768; size_t extend_lds = 0; uint32_t stack_entries = 8, node_lanes = kNodeLanes, owner_lanes = 64;
     ~mi355pt_render() {
         for (auto& e : events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
         for (void* p : allocs) (void)hipFree(p);
@@ -827,7 +836,7 @@ int mi355pt_scene_create(const mi355pt_scene_desc* desc, int32_t device, mi355pt
         if ((uint64_t)tri_base + flat.slot_face.size() > (uint64_t)kLeafSlotMask) return fail(MI355PT_ERR_TOO_LARGE, "more than 2^27 triangles");
         d.face_base = (uint32_t)(faces.size() / 4); d.vert_base = (uint32_t)(normals.size() / 3);
         d.has_tangents = (s.tangents && s.bitangents) ? 1 : 0; d.pad = 0;
-        const bool root_internal = flat.root_cnt == ptb::kInternal;
+        const bool root_internal = flat.root_cnt >= ptb::kChain;
         d.root_ref = root_internal ? node_base : tri_base + flat.root_ref; d.root_cnt = flat.root_cnt;
         // node records: rebase references to the global pools
         const size_t nrec = flat.node_words.size() / 16;
@@ -835,7 +844,7 @@ int mi355pt_scene_create(const mi355pt_scene_desc* desc, int32_t device, mi355pt
         for (size_t r = 0; r < nrec; r++) {
             float w[16]; memcpy(w, &flat.node_words[16 * r], sizeof(w));
             uint32_t u[4]; memcpy(u, &w[12], sizeof(u));
-            for (int c = 0; c < 2; c++) u[c] += (u[2 + c] == ptb::kInternal) ? node_base : tri_base;
+            for (int c = 0; c < 2; c++) u[c] += (u[2 + c] >= ptb::kChain) ? node_base : tri_base;
             memcpy(&w[12], u, sizeof(u));
             memcpy(&bvh_nodes[4 * ((size_t)node_base + r)], w, sizeof(w));
         }
@@ -971,19 +980,22 @@ int mi355pt_render_create(mi355pt_scene* scene, const mi355pt_render_params* par
     HIP_TRY(hipMemsetAsync(r->rgb8, 0, npix * 3, r->stream));
     HIP_TRY(hipStreamSynchronize(r->stream));
     hipDeviceProp_t prop; HIP_TRY(hipGetDeviceProperties(&prop, scene->device));
-    HIP_TRY(dalloc((void**)&P.coop, (size_t)prop.multiProcessorCount * 8 * (kBlock / 64) * kCoopStride * sizeof(unsigned long long)));
     r->grid = prop.multiProcessorCount * 8;
-    {   // persistent extend kernel: LDS stack of (tree depth + 4) dwords per lane; grid = resident blocks only
+    {   // persistent extend kernel: one wave per workgroup, LDS = stack of (tree depth + 4) dwords per lane + the wave's
+        // queues; the grid is the number of waves that are resident at once
         const int entries = std::min(kStackSize, std::max(8, scene->max_depth + 4));
         r->stack_entries = (uint32_t)entries;
-        r->extend_lds = (size_t)(entries + kLeafCap) * kBlock * 4;
-        const int by_lds = (int)((size_t)160 * 1024 / r->extend_lds), by_vgpr = 5;
-        r->extend_grid = prop.multiProcessorCount * std::max(1, std::min(by_lds, by_vgpr));
+        r->extend_lds = extend_lds_bytes((uint32_t)entries);
+        int waves = 0;
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&waves, k_extend<false>, kExtBlock, r->extend_lds));
+        if (const char* e = getenv("MI355PT_EXTEND_WAVES_PER_CU")) waves = std::min(waves, std::max(1, atoi(e)));
+        r->extend_grid = prop.multiProcessorCount * std::max(1, waves);
     }
-    if (const char* e = getenv("MI355PT_EXTEND_BLOCKS_PER_CU")) r->extend_grid = prop.multiProcessorCount * std::max(1, atoi(e));
+    // test knobs: results must not depend on either (tests/test_gpu_parity.py::test_traversal_schedule_*)
+    if (const char* e = getenv("MI355PT_NODE_LANES")) r->node_lanes = (uint32_t)std::min(64, std::max(1, atoi(e)));
+    if (const char* e = getenv("MI355PT_OWNER_LANES")) r->owner_lanes = (uint32_t)std::min(64, std::max(1, atoi(e)));
     r->count_work = getenv("MI355PT_COUNT_WORK") != nullptr;
-    if (getenv("MI355PT_VERBOSE")) fprintf(stderr, "mi355pt: tree depth %d, extend grid %d blocks, LDS %zu B/block, long_ray %u\n", scene->max_depth, r->extend_grid, r->extend_lds, r->long_ray);
-    if (const char* e = getenv("MI355PT_LONG_RAY")) r->long_ray = (uint32_t)strtoul(e, nullptr, 10);
+    if (getenv("MI355PT_VERBOSE")) fprintf(stderr, "mi355pt: tree depth %d, extend grid %d waves, LDS %zu B/wave\n", scene->max_depth, r->extend_grid, r->extend_lds);
     *out = r.release();
     return MI355PT_OK;
 }
@@ -1027,17 +1039,18 @@ void drain_events(mi355pt_render* r) {
 int run_paths(mi355pt_render* r, uint32_t n, uint32_t jitter = 1, uint32_t only_extend = 0) {
     DPaths& P = r->P; const mi355pt_render_params& p = r->prm;
     const DScene& S = r->scene->d;
-    Params prm{p.seed, p.width, p.height, p.max_bounces, p.rr_start, r->long_ray, r->stack_entries};
+    Params prm{p.seed, p.width, p.height, p.max_bounces, p.rr_start, r->stack_entries, r->node_lanes, r->owner_lanes};
     const size_t nb = p.max_bounces + 2;
     HIP_TRY(hipMemsetAsync(P.counts, 0, nb * 4, r->stream));
     HIP_TRY(hipMemsetAsync(P.scounts, 0, nb * 4, r->stream));
     HIP_TRY(hipMemsetAsync(P.work, 0, nb * 4, r->stream));
     const int g = grid_for(r, n);
-    const int ge = (int)std::min<size_t>((size_t)g, (size_t)r->extend_grid);     // persistent: resident waves only
+    const int ge = (int)std::max<size_t>(1, std::min<size_t>(((size_t)n + 63) / 64, (size_t)r->extend_grid));     // persistent: resident waves only
+    if (jitter != 2) hipLaunchKernelGGL(k_raygen, dim3(g), dim3(kBlock), 0, r->stream, r->cam, P, prm, n, jitter);
     for (uint32_t b = 0; b < (only_extend ? 1u : p.max_bounces); b++) {
         ev_begin(r, 0);
-        if (r->count_work) hipLaunchKernelGGL(k_extend<true>, dim3(ge), dim3(kBlock), r->extend_lds, r->stream, S, r->cam, P, prm, b, n, jitter);
-        else hipLaunchKernelGGL(k_extend<false>, dim3(ge), dim3(kBlock), r->extend_lds, r->stream, S, r->cam, P, prm, b, n, jitter);
+        if (r->count_work) hipLaunchKernelGGL(k_extend<true>, dim3(ge), dim3(kExtBlock), r->extend_lds, r->stream, S, P, prm, b, n);
+        else hipLaunchKernelGGL(k_extend<false>, dim3(ge), dim3(kExtBlock), r->extend_lds, r->stream, S, P, prm, b, n);
         ev_end(r);
         if (only_extend) break;
         ev_begin(r, 1);
@@ -1064,7 +1077,7 @@ int mi355pt_render_step(mi355pt_render* r, uint32_t spp) {
     const size_t npix = (size_t)p.width * p.height, cap = r->P.cap;
     const size_t ppc = std::min(npix, cap);
     const size_t spc = ppc == npix ? std::max<size_t>(1, cap / npix) : 1;
-    const Params kprm{p.seed, p.width, p.height, p.max_bounces, p.rr_start, r->long_ray, r->stack_entries};
+    const Params kprm{p.seed, p.width, p.height, p.max_bounces, p.rr_start, r->stack_entries, r->node_lanes, r->owner_lanes};
     for (size_t pix_base = 0; pix_base < npix; pix_base += ppc) {
         const uint32_t np = (uint32_t)std::min(ppc, npix - pix_base);
         for (uint32_t s0 = 0; s0 < spp; s0 += (uint32_t)spc) {
@@ -1089,6 +1102,9 @@ int mi355pt_render_sync(mi355pt_render* r) {
     HIP_TRY(hipSetDevice(r->scene->device));
     HIP_TRY(hipStreamSynchronize(r->stream));
     drain_events(r);
+    unsigned long long guard = 0;
+    HIP_TRY(hipMemcpy(&guard, r->P.stat + 15, sizeof(guard), hipMemcpyDeviceToHost));
+    if (guard) return fail(MI355PT_ERR_HIP, "k_extend gave up: a wave exceeded its pass limit (results are incomplete)");
     return MI355PT_OK;
 }
 
@@ -1129,7 +1145,7 @@ int mi355pt_trace_primary(mi355pt_render* r, uint32_t x0, uint32_t y0, uint32_t 
     int32_t *dn, *dm, *df; float* dt;
     HIP_TRY(hipMalloc((void**)&dn, n * 4)); HIP_TRY(hipMalloc((void**)&dm, n * 4)); HIP_TRY(hipMalloc((void**)&df, n * 4)); HIP_TRY(hipMalloc((void**)&dt, n * 4));
     const mi355pt_render_params& p = r->prm;
-    Params prm{p.seed, p.width, p.height, p.max_bounces, p.rr_start, r->long_ray, r->stack_entries};
+    Params prm{p.seed, p.width, p.height, p.max_bounces, p.rr_start, r->stack_entries, r->node_lanes, r->owner_lanes};
     if (n > r->P.cap) { (void)hipFree(dn); (void)hipFree(dm); (void)hipFree(df); (void)hipFree(dt); return fail(MI355PT_ERR_TOO_LARGE, "rectangle larger than the path pool"); }
     hipLaunchKernelGGL(k_primary_init, dim3(grid_for(r, n)), dim3(kBlock), 0, r->stream, r->P, prm, x0, y0, rw, rh);
     const int rc = run_paths(r, (uint32_t)n, 0, 1);
@@ -1185,7 +1201,7 @@ int mi355pt_sample_radiance(mi355pt_render* r, const uint32_t* pixel, const uint
     HIP_TRY(hipMalloc((void**)&dl, (size_t)count * 12)); HIP_TRY(hipMalloc((void**)&dm, (size_t)count * 12));
     HIP_TRY(hipMemcpy(dp, pixel, (size_t)count * 4, hipMemcpyHostToDevice)); HIP_TRY(hipMemcpy(ds, sample, (size_t)count * 4, hipMemcpyHostToDevice));
     const mi355pt_render_params& p = r->prm;
-    const Params kprm{p.seed, p.width, p.height, p.max_bounces, p.rr_start, r->long_ray, r->stack_entries};
+    const Params kprm{p.seed, p.width, p.height, p.max_bounces, p.rr_start, r->stack_entries, r->node_lanes, r->owner_lanes};
     hipLaunchKernelGGL(k_init, dim3(grid_for(r, count)), dim3(kBlock), 0, r->stream, r->P, kprm,
                        count, 0u, 1u, (const uint32_t*)r->cnt, 0u, 1u, (const uint32_t*)dp, (const uint32_t*)ds);
     int rc = run_paths(r, count);

@@ -250,6 +250,26 @@ PT_DEV bool tri_closest(const Tri& T, F3 o, F3 d, int side, uint32_t slot, float
     bt = t; bslot = slot;
     return true;
 }
+// The same test against a packed (t, slot) key (see hit_key in mi355pt.hip): returns true, and the candidate's key,
+// when the candidate is inside the triangle and strictly better than `cur`.
+PT_DEV bool tri_closest_key(const Tri& T, F3 o, F3 d, uint32_t slot, unsigned long long cur, unsigned long long& ck) {
+    const F3 v01 = T.v1 - T.v0, v02 = T.v2 - T.v0;
+    const F3 n = gcross(v01, v02);
+    const float dn = gdot(d, n);
+    if (fabsf(dn) <= kFltEps) return false;
+    const float t = (gdot(T.v0, n) - gdot(o, n)) / dn;
+    if (t < 0.0f) return false;
+    const uint32_t tb = __float_as_uint(t);
+    ck = ((unsigned long long)((t == 0.0f) ? 0u : tb) << 32) | (unsigned long long)((slot << 1) | (tb == 0x80000000u ? 1u : 0u));
+    if (!(ck < cur)) return false;                 // also rejects a NaN distance, as the reference's `z < best.z` does
+    const F3 P = o + d * t;
+    float a0, a1, a2, a;
+    tri_areas<true>(neg(d), v01, v02, T.v0, T.v1, T.v2, P, a0, a1, a2, a);
+    if (a0 <= 0.0f) return false;
+    if (a1 <= 0.0f) return false;
+    if (a2 <= 0.0f) return false;
+    return true;
+}
 // Any-hit form for visibility (raytracer.cpp:99-130): front faces only, accepted iff t < bound.
 PT_DEV bool tri_any_front(const Tri& T, F3 o, F3 d, float bound) {
     const F3 v01 = T.v1 - T.v0, v02 = T.v2 - T.v0;
@@ -274,6 +294,7 @@ PT_DEV bool tri_any_front(const Tri& T, F3 o, F3 d, float bound) {
 constexpr int kStackSize = 48;        // entries per lane; host checks tree depth + 4 <= kStackSize
 constexpr int kTravBlock = 256;       // threads per block of every kernel that traverses
 constexpr uint32_t kLeafFlag = 0x80000000u, kLeafSlotMask = 0x07FFFFFFu;   // leaf entry: flag | count<<27 | first slot
+constexpr uint32_t kInternal = 0xFFFFFFFFu, kChain = 0xFFFFFFFEu;         // count words of a node record (bvh_build.h)
 struct WorkCounters { uint32_t nodes, tris; };
 
 // Traversal stack: node / leaf references live in LDS (one dword per entry, entry e of lane l at
@@ -299,10 +320,12 @@ PT_DEV bool traverse_mesh(const DScene& S, const DMesh& M, F3 o, F3 d, F3 inv, i
             first += c; cnt -= c;
         }
     };
-    if (M.root_cnt == 0xFFFFFFFFu) {
+    if (M.root_cnt == kInternal) {
         float tn;
         if (COUNT) wc.nodes++;
         if (!slab(M.root_bound, o, inv, tn)) return false;
+        PT_STK(0) = M.root_ref; stack_t[0] = -kBig; sp = 1;
+    } else if (M.root_cnt == kChain) {
         PT_STK(0) = M.root_ref; stack_t[0] = -kBig; sp = 1;
     } else {
         push_leaf(M.root_ref, M.root_cnt);
@@ -322,8 +345,10 @@ PT_DEV bool traverse_mesh(const DScene& S, const DMesh& M, F3 o, F3 d, F3 inv, i
             const uint32_t lref = __float_as_uint(w3.x), rref = __float_as_uint(w3.y), lcnt = __float_as_uint(w3.z), rcnt = __float_as_uint(w3.w);
             float tl = -kBig, tr = -kBig;
             bool hl = false, hr = false;
-            if (lcnt == 0xFFFFFFFFu) { hl = slab(lb, o, inv, tl); if (beyond(tl, bt, pabs)) hl = false; }
-            if (rcnt == 0xFFFFFFFFu) { hr = slab(rb, o, inv, tr); if (beyond(tr, bt, pabs)) hr = false; }
+            if (lcnt == kInternal) { hl = slab(lb, o, inv, tl); if (beyond(tl, bt, pabs)) hl = false; }
+            else if (lcnt == kChain) hl = true;                   // chain records carry no bound (bvh_build.h)
+            if (rcnt == kInternal) { hr = slab(rb, o, inv, tr); if (beyond(tr, bt, pabs)) hr = false; }
+            else if (rcnt == kChain) hr = true;
             // internal children: far first, so the near one is popped first; leaves last, so they are
             // popped before either (cheap, and they shrink the pruning distance early)
             const bool left_first = !(tr < tl);
@@ -334,8 +359,8 @@ PT_DEV bool traverse_mesh(const DScene& S, const DMesh& M, F3 o, F3 d, F3 inv, i
                 }
             } else if (hl) { if (sp < kStackSize) { PT_STK(sp) = lref; stack_t[sp] = tl; sp++; } }
             else if (hr) { if (sp < kStackSize) { PT_STK(sp) = rref; stack_t[sp] = tr; sp++; } }
-            if (lcnt != 0xFFFFFFFFu) push_leaf(lref, lcnt);
-            if (rcnt != 0xFFFFFFFFu) push_leaf(rref, rcnt);
+            if (lcnt < kChain) push_leaf(lref, lcnt);
+            if (rcnt < kChain) push_leaf(rref, rcnt);
         }
         if (lc == 0) { if (sp == 0) break; else continue; }
         for (uint32_t k = 0; k < lc; k++) {

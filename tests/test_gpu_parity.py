@@ -155,11 +155,13 @@ def test_errors_are_loud(built):
 
 
 @pytest.mark.parametrize("name", ["teapot_cornell", "grid_small", "textured_c2"])
-def test_cooperative_traversal_same_results(built, name, monkeypatch):
-    """MI355PT_LONG_RAY=0 finishes EVERY traversal with the wave-cooperative shared-stack walk; hits and
-    radiance must not depend on the visiting order."""
+def test_traversal_schedule_same_results(built, name, monkeypatch):
+    """MI355PT_OWNER_LANES=3 lets only 3 lanes of a wave own rays: the other 61 steal subtrees all the time;
+    MI355PT_NODE_LANES=64 drains the leaf queue after almost every node step.  Hits and radiance must not
+    depend on who walks which subtree, or when its triangles are tested."""
     s, orc, pt, w, h = built(name)
-    monkeypatch.setenv("MI355PT_LONG_RAY", "0")
+    monkeypatch.setenv("MI355PT_OWNER_LANES", "3")
+    monkeypatch.setenv("MI355PT_NODE_LANES", "64")
     p2 = PathTracer(pt.dscene)
     p2.Init(w, h)
     node, mesh, face, t = p2.trace_primary()
@@ -195,7 +197,8 @@ def test_full_size_10m_triangle_scene(monkeypatch):
     pixel = rng.integers(0, w * h, 200000).astype(np.uint32)
     sample = rng.integers(0, 16, 200000).astype(np.uint32)
     a, _ = pt.sample_radiance(pixel, sample)
-    monkeypatch.setenv("MI355PT_LONG_RAY", "0")
+    monkeypatch.setenv("MI355PT_OWNER_LANES", "5")
+    monkeypatch.setenv("MI355PT_NODE_LANES", "8")
     p2 = PathTracer(pt.dscene)
     p2.Init(w, h)
     b, _ = p2.sample_radiance(pixel, sample)
@@ -216,14 +219,14 @@ def _model_meshes(node, out):
 
 
 @pytest.mark.parametrize("name", ["teapot_cornell", "grid_small"])
-@pytest.mark.parametrize("long_ray", ["128", "0"])
-def test_secondary_rays_from_surfaces(built, name, long_ray, monkeypatch):
+@pytest.mark.parametrize("owner_lanes", ["64", "2"])
+def test_secondary_rays_from_surfaces(built, name, owner_lanes, monkeypatch):
     """mi355pt_trace_rays on rays that start 1e-4 off a mesh surface in random directions -- the shape of
     every bounce and shadow ray.  About 1 % of them have a reference hit at t = -0.0 (the plane-distance
     numerator cancels to zero and model.cpp's `t < 0` does not reject it): those must be reported as
-    the reference reports them, by both the per-lane and the wave-cooperative traversal."""
+    the reference reports them, whether a ray is walked by its own lane or by stealing lanes."""
     s, orc, pt, w, h = built(name)
-    monkeypatch.setenv("MI355PT_LONG_RAY", long_ray)
+    monkeypatch.setenv("MI355PT_OWNER_LANES", owner_lanes)
     p2 = PathTracer(pt.dscene)
     p2.Init(w, h)
     m = _model_meshes(s.rootNode, [])[0]

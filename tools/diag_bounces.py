@@ -13,13 +13,11 @@ for mb in (1, 2, 3, 4, 6):
     pt.render(1)
     pt.reset_stats(); pt.set_profiling(True, False); pt.render(1); t = pt.stats()
     pt.reset_stats(); pt.set_profiling(False, True); pt.render(1); c = pt.stats()
-    dbg = c["debug"]
-    cur = dict(outer=dbg[0] & 0xFFFFFFFF, total=dbg[0] >> 32, nit=dbg[1], nact=dbg[2], tit=dbg[3], tact=dbg[4], load=dbg[5], cnode=dbg[6], ctri=dbg[7], rays=c["closest_rays"], nodes=c["bvh_node_visits"], tris=c["bvh_tri_tests"], ext=t["extend_ms"], sh=t["shade_ms"], co=t["connect_ms"],
+    cur = dict(rays=c["closest_rays"], nodes=c["bvh_node_visits"], tris=c["bvh_tri_tests"], ext=t["extend_ms"], sh=t["shade_ms"], co=t["connect_ms"],
                srays=c["shadow_rays"], snodes=c["shadow_node_visits"], stris=c["shadow_tri_tests"])
     d = cur if prev is None else {k: cur[k] - prev[k] for k in cur}
     print(f"bounces<{mb}: closest rays {d['rays']:>9d} nodes/ray {d['nodes']/max(d['rays'],1):6.1f} tris/ray {d['tris']/max(d['rays'],1):5.1f} extend {d['ext']:7.2f} ms "
           f"({d['rays']/max(d['ext'],1e-9)/1e3:7.1f} Mrays/s) | shadow rays {d['srays']:>9d} nodes/ray {d['snodes']/max(d['srays'],1):6.1f} tris/ray {d['stris']/max(d['srays'],1):5.1f} "
-          f"connect {d['co']:6.2f} ms shade {d['sh']:6.2f} ms | max nodes/ray so far {c['max_nodes_per_ray']}", flush=True)
-    print(f"      wave loop iters {d['outer']:>10d}  node-phase iters {d['nit']:>10d} lanes/iter {d['nact']/max(d['nit'],1):5.1f}  tri-phase iters {d['tit']:>10d} lanes/iter {d['tact']/max(d['tit'],1):5.1f}  | wave cycles total {d['total']:.3e} node-phase {d['cnode']:.3e} (load wait {d['load']:.3e}) tri-phase {d['ctri']:.3e}; per node iter {d['cnode']/max(d['nit'],1):.0f} (load {d['load']/max(d['nit'],1):.0f}) per tri iter {d['ctri']/max(d['tit'],1):.0f}", flush=True)
+          f"connect {d['co']:6.2f} ms shade {d['sh']:6.2f} ms", flush=True)
     prev = cur
     pt.close_render()
