@@ -44,6 +44,10 @@ struct DPaths {
     uint32_t *squeue;     // slots with shadow work this bounce
     uint32_t *counts;     // [b] = #paths entering bounce b (b >= 1)
     uint32_t *scounts;    // [b] = #paths with shadow work at bounce b
+    uint32_t *vqueue;     // visibility items of this bounce: slot * 2 + which (0 = light sample, 1 = MIS BRDF sample)
+    uint32_t *vcounts;    // [b] = #visibility items at bounce b
+    uint32_t *vwork;      // [b] = next vqueue index to hand out in k_trace<ANY>
+    uint8_t  *vis;        // [2 x cap] 1 = blocked, per visibility item
     uint32_t *work;       // [b] = next queue index to hand out in k_extend of bounce b (persistent refill)
     unsigned long long *stat;   // [0] closest rays [1] shadow rays [2] samples [3,4] extend node visits / tri tests [5,6] connect ditto
 };
@@ -153,11 +157,15 @@ __device__ __forceinline__ unsigned long long hit_key(float t, uint32_t slot) {
 }
 __device__ __forceinline__ float key_dist(unsigned long long k) { return (k & 1ull) ? -0.0f : __uint_as_float((uint32_t)(k >> 32)); }
 
-template <bool COUNT>
-__global__ void __launch_bounds__(kExtBlock) k_extend(DScene S, DPaths P, Params prm, uint32_t bounce, uint32_t n0) {
-    const uint32_t n = bounce == 0 ? n0 : P.counts[bounce];
-    const uint32_t* q = bounce == 0 ? nullptr : P.queue[bounce & 1];
-    uint32_t* work = &P.work[bounce];
+//
+// ANY = false: closest hit of the rays in P.ray (k_extend).  ANY = true: LightVisTest's sweep over the objects that are
+// not the light (raytracer.cpp:99-152) for the visibility items queued by k_shade: an item is blocked by any
+// front-face hit nearer than min(tmax, distance to the light); the walk of a blocked ray is abandoned at once.
+template <bool ANY, bool COUNT>
+__global__ void __launch_bounds__(kExtBlock) k_trace(DScene S, DPaths P, Params prm, uint32_t bounce, uint32_t n0) {
+    const uint32_t n = ANY ? P.vcounts[bounce] : (bounce == 0 ? n0 : P.counts[bounce]);
+    const uint32_t* q = ANY ? P.vqueue : (bounce == 0 ? nullptr : P.queue[bounce & 1]);
+    uint32_t* work = ANY ? &P.vwork[bounce] : &P.work[bounce];
     const size_t cap = P.cap;
     extern __shared__ uint32_t sm[];
     const uint32_t lane = threadIdx.x;
@@ -172,27 +180,40 @@ __global__ void __launch_bounds__(kExtBlock) k_extend(DScene S, DPaths P, Params
     uint8_t* tril = (uint8_t*)(aux + kLdsTri);                   // [256] expanded triangle list of one drain round
 #define PT_STK(i) stk[(i) * 64 + lane]
     WorkCounters wc; wc.nodes = 0; wc.tris = 0;
-    uint32_t state = LS_IDLE, slot = 0, ii = 0, mi = 0, sp = 0, sb = 0, owner = lane;
+    uint32_t state = LS_IDLE, slot = 0, rec = 0, sp = 0, sb = 0, owner = lane;
     F3 o = f3(0, 0, 0), inv = f3(0, 0, 0);
     float bt = kBig, pabs = 0.0f;
-    float best_t = kBig; int best_inst = -1, best_mesh = -1; uint32_t best_slot = 0;
+    float best_t = kBig; int best_inst = -1, best_mesh = -1; uint32_t best_slot = 0;      // closest: best over the objects so far
+    float bound = 0.0f; uint32_t linst = 0;                                                // any: distance bound, the light's object
+    auto load_world = [&](uint32_t it, Ray& wr) {                // closest: `it` is a path slot; any: slot * 2 + which
+        if (!ANY) {
+            wr.p = f3(P.ray[it], P.ray[cap + it], P.ray[2 * cap + it]);
+            wr.d = f3(P.ray[3 * cap + it], P.ray[4 * cap + it], P.ray[5 * cap + it]);
+        } else {
+            const float* sh = P.sh + (it >> 1);
+            wr.p = f3(sh[(size_t)SH_OX * cap], sh[(size_t)SH_OY * cap], sh[(size_t)SH_OZ * cap]);
+            wr.d = (it & 1u) ? f3(sh[(size_t)SH_W2X * cap], sh[(size_t)SH_W2Y * cap], sh[(size_t)SH_W2Z * cap])
+                             : f3(sh[(size_t)SH_W1X * cap], sh[(size_t)SH_W1Y * cap], sh[(size_t)SH_W1Z * cap]);
+        }
+    };
     uint32_t qh = 0, nq = 0;                                     // leaf queue (ring): head, count -- wave-uniform
     const uint32_t nwaves = gridDim.x;
     uint32_t chunk = (n / (8u * nwaves)) & ~63u; chunk = chunk < 64u ? 64u : (chunk > 1024u ? 1024u : chunk);
     uint32_t pool_next = 0, pool_end = 0; bool exhausted = false;
     uint32_t guard = 0;
+    // counting builds: wave cycles per phase, passes, node-loop lanes (stats.debug, tools/diag_bounces.py)
+    unsigned long long ck_setup = 0, ck_node = 0, ck_drain = 0, ck_rest = 0, n_node_it = 0, n_node_act = 0, n_drain_it = 0, n_drain_act = 0;
+    unsigned long long ck0 = COUNT ? clock64() : 0;
+#define PT_PHASE(acc) do { if (COUNT) { const unsigned long long now_ = clock64(); acc += now_ - ck0; ck0 = now_; } } while (0)
 
     for (;;) {
         // every pass makes progress (a node step, a drained queue, a finished mesh or a new ray), so a wave needs a few
-        // thousand passes; the guard turns a scheduling bug into an error code (stat[15]) instead of a hung GPU
-        if (++guard > kExtendGuard) { if (lane == 0) atomicOr(&P.stat[15], 1ull); break; }
+        // thousand passes; the guard turns a scheduling bug into an error code (stat[7]) instead of a hung GPU
+        if (++guard > kExtendGuard) { if (lane == 0) atomicOr(&P.stat[7], 1ull); break; }
         // ================= setup: new rays for idle lanes, next object / mesh for lanes between meshes
         {
             Ray wr; wr.p = wr.d = f3(0, 0, 0);
-            if (state == LS_SETUP) {
-                wr.p = f3(P.ray[slot], P.ray[cap + slot], P.ray[2 * cap + slot]);
-                wr.d = f3(P.ray[3 * cap + slot], P.ray[4 * cap + slot], P.ray[5 * cap + slot]);
-            }
+            if (state == LS_SETUP) load_world(slot, wr);
             for (;;) {
                 if (state == LS_IDLE && lane >= prm.owner_lanes) state = LS_DONE;     // test knob: these lanes only ever steal
                 const unsigned long long need = __ballot(state == LS_IDLE);
@@ -208,57 +229,77 @@ __global__ void __launch_bounds__(kExtBlock) k_extend(DScene S, DPaths P, Params
                         const uint32_t idx = pool_next + (uint32_t)__popcll(need & lt);
                         if (idx < pool_end) {
                             slot = q ? q[idx] : idx;
-                            wr.p = f3(P.ray[slot], P.ray[cap + slot], P.ray[2 * cap + slot]);
-                            wr.d = f3(P.ray[3 * cap + slot], P.ray[4 * cap + slot], P.ray[5 * cap + slot]);
-                            best_t = kBig; best_inst = -1; best_mesh = -1; best_slot = 0;
-                            ii = 0; mi = 0; state = LS_SETUP;
+                            load_world(slot, wr);
+                            rec = 0; state = LS_SETUP;
+                            if (!ANY) { best_t = kBig; best_inst = -1; best_mesh = -1; best_slot = 0; }
+                            else {
+                                // (1) the light's own object, both sides: a miss or its back side blocks (raytracer.cpp:67-97,138-145)
+                                const float* sh = P.sh + (slot >> 1);
+                                const float tmax = (slot & 1u) ? kBig : sh[(size_t)SH_TMAX1 * cap];
+                                const DLight& L = S.lights[__float_as_int(sh[(size_t)SH_LIGHT * cap])];
+                                linst = (uint32_t)L.inst;
+                                const float4* R = S.recs + (size_t)L.rec * kRecStride;
+                                const Ray lr = rec_ray(S, R, __float_as_uint(R[0].y), linst, wr);
+                                float lz; bool front; F3 Pp;
+                                if (!plane_hit(lr.p, lr.d, SIDE_BOTH, lz, front, Pp) || !front) { P.vis[slot] = 1; state = LS_IDLE; }
+                                else bound = tmax < lz ? tmax : lz;              // (2) blocks iff z < tmax && z < lightZ
+                            }
                         } else if (exhausted) state = LS_DONE;
                     }
                     const uint32_t took = (uint32_t)__popcll(need);
                     pool_next = pool_end - pool_next < took ? pool_end : pool_next + took;
                 }
                 if (__ballot(state == LS_SETUP || state == LS_IDLE) == 0) break;
-                // ---- one step of TraceNode's walk over the objects (earlier object wins ties, raytracer.cpp:208,238)
+                // ---- TraceNode's / LightVisTest's walk over the objects (earlier object wins ties, raytracer.cpp:208,238),
+                // record by record, until a mesh has to be traversed or the ray is finished
                 uint32_t root_leaf = 0;                               // leaf item to enqueue when a mesh's root is a leaf
                 if (state == LS_SETUP) {
-                    if (ii >= (uint32_t)S.num_insts) {
-                        P.ht[slot] = best_t; P.hinst[slot] = best_inst; P.hmesh[slot] = best_mesh; P.hslot[slot] = best_slot;
-                        state = LS_IDLE;
-                    } else {
-                        const DInst& in = S.insts[ii];
-                        const Ray lr = to_inst(S, in, wr);
-                        if (in.kind == MI355PT_OBJ_PLANE) {
+                    for (;;) {
+                        if (rec >= (uint32_t)S.num_recs) {
+                            if (ANY) P.vis[slot] = 0;
+                            else { P.ht[slot] = best_t; P.hinst[slot] = best_inst; P.hmesh[slot] = best_mesh; P.hslot[slot] = best_slot; }
+                            state = LS_IDLE;
+                            break;
+                        }
+                        const float4* R = S.recs + (size_t)rec * kRecStride;
+                        const float4 h0 = R[0], h1 = R[1];
+                        const uint32_t kind = __float_as_uint(h0.x), clen = __float_as_uint(h0.y), nexti = __float_as_uint(h0.z), rflags = __float_as_uint(h0.w);
+                        const uint32_t rii = __float_as_uint(h1.x);
+                        if (ANY && rii == linst) { rec = nexti; continue; }           // the light's own object is not an occluder
+                        const Ray lr = rec_ray(S, R, clen, rii, wr);
+                        if (kind == MI355PT_OBJ_PLANE) {
                             float t; bool front; F3 Pp;
-                            if (plane_hit(lr.p, lr.d, SIDE_BOTH, t, front, Pp) && t < best_t) { best_t = t; best_inst = (int)ii; best_mesh = -1; best_slot = 0; }
-                            ii++;
-                        } else if (in.kind == MI355PT_OBJ_MODEL) {
-                            const DModel& mo = S.models[in.model];
-                            const F3 linv = f3(1.0f, 1.0f, 1.0f) / lr.d;
-                            float tn;
-                            if (mi >= (uint32_t)mo.num_meshes || (mi == 0 && !slab(mo.aabb, lr.p, linv, tn))) { ii++; mi = 0; }   // model.cpp:212
-                            else {
-                                const DMesh& M = S.meshes[mo.first_mesh + mi];                                        // model.cpp:223-245
-                                bool go = slab(M.aabb, lr.p, linv, tn);
-                                if (go && M.root_cnt == kInternal) { if (COUNT) wc.nodes++; go = slab(M.root_bound, lr.p, linv, tn); }
-                                if (go && M.root_cnt == 0u) go = false;
-                                if (!go) mi++;
-                                else {
-                                    // the mesh starts from the best so far with slot key 0: an equal-t candidate of a later
-                                    // mesh / object loses (model.cpp:237), only a strictly closer one replaces it
-                                    rayl[2 * lane] = make_float4(lr.p.x, lr.p.y, lr.p.z, 0.0f);
-                                    rayl[2 * lane + 1] = make_float4(lr.d.x, lr.d.y, lr.d.z, 0.0f);
-                                    keyl[lane] = hit_key(best_t, 0u) & ~1ull;
-                                    owner = lane; sb = 0;
-                                    if (M.root_cnt >= kChain) {
-                                        o = lr.p; inv = linv; pabs = prune_abs(lr.p); bt = best_t;
-                                        PT_STK(0) = M.root_ref; sp = 1; nwork[lane] = 1; state = LS_TRAV;
-                                    } else {
-                                        root_leaf = kLeafFlag | ((M.root_cnt - 1u) << 27) | M.root_ref;
-                                        sp = 0; nwork[lane] = 0; state = LS_WAIT;
-                                    }
-                                }
-                            }
-                        } else ii++;
+                            if (ANY) {
+                                if (plane_hit(lr.p, lr.d, SIDE_FRONT, t, front, Pp) && t < bound) { P.vis[slot] = 1; state = LS_IDLE; break; }
+                            } else if (plane_hit(lr.p, lr.d, SIDE_BOTH, t, front, Pp) && t < best_t) { best_t = t; best_inst = (int)rii; best_mesh = -1; best_slot = 0; }
+                            rec = nexti;
+                            continue;
+                        }
+                        const F3 linv = f3(1.0f, 1.0f, 1.0f) / lr.d;
+                        const float4 b0 = R[2], b1 = R[3], b2 = R[4], b3 = R[5], b4 = R[6];
+                        const float model_box[6] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y}, mesh_box[6] = {b1.z, b1.w, b2.x, b2.y, b2.z, b2.w};
+                        const float root_box[6] = {b3.x, b3.y, b3.z, b3.w, b4.x, b4.y};
+                        const uint32_t root_ref = __float_as_uint(h1.z), root_cnt = __float_as_uint(h1.w);
+                        float tn;
+                        if ((rflags & 1u) && !slab(model_box, lr.p, linv, tn)) { rec = nexti; continue; }      // Model::IntersectRay, model.cpp:212
+                        bool go = slab(mesh_box, lr.p, linv, tn);                                              // model.cpp:223-245
+                        if (go && root_cnt == kInternal) { if (COUNT) wc.nodes++; go = slab(root_box, lr.p, linv, tn); }
+                        if (go && root_cnt == 0u) go = false;
+                        if (!go) { rec++; continue; }
+                        // the mesh starts from the best so far with slot key 0: an equal-t candidate of a later
+                        // mesh / object loses (model.cpp:237), only a strictly closer one replaces it
+                        rayl[2 * lane] = make_float4(lr.p.x, lr.p.y, lr.p.z, bound);
+                        rayl[2 * lane + 1] = make_float4(lr.d.x, lr.d.y, lr.d.z, 0.0f);
+                        keyl[lane] = ANY ? 0ull : hit_key(best_t, 0u) & ~1ull;       // any: 1 = blocked
+                        owner = lane; sb = 0;
+                        if (root_cnt >= kChain) {
+                            o = lr.p; inv = linv; pabs = prune_abs(lr.p); bt = ANY ? bound : best_t;
+                            PT_STK(0) = root_ref; sp = 1; nwork[lane] = 1; state = LS_TRAV;
+                        } else {
+                            root_leaf = kLeafFlag | ((root_cnt - 1u) << 27) | root_ref;
+                            sp = 0; nwork[lane] = 0; state = LS_WAIT;
+                        }
+                        break;
                     }
                 }
                 const unsigned long long rl = __ballot(root_leaf != 0u);
@@ -268,6 +309,7 @@ __global__ void __launch_bounds__(kExtBlock) k_extend(DScene S, DPaths P, Params
                 }
             }
         }
+        PT_PHASE(ck_setup);
         if (__ballot(state != LS_DONE) == 0) break;
         __syncthreads();
         // ================= node steps, while most lanes can take one
@@ -280,6 +322,7 @@ __global__ void __launch_bounds__(kExtBlock) k_extend(DScene S, DPaths P, Params
                 const uint32_t nw = (uint32_t)__popcll(__ballot(want));
                 if (nw == 0 || (!first && nw < th) || kLeafQ - nq < 128u) break;
                 first = false;
+                if (COUNT) { n_node_it++; n_node_act += nw; }
                 uint32_t leafL = 0, leafR = 0;
                 if (want) {
                     sp--;
@@ -344,6 +387,7 @@ __global__ void __launch_bounds__(kExtBlock) k_extend(DScene S, DPaths P, Params
             }
         }
         __syncthreads();
+        PT_PHASE(ck_node);
         // ================= drain the leaf queue: one triangle per lane per pass, whatever ray it belongs to
         while (nq > 0) {
             const uint32_t m = nq < 64u ? nq : 64u;
@@ -357,6 +401,7 @@ __global__ void __launch_bounds__(kExtBlock) k_extend(DScene S, DPaths P, Params
             __syncthreads();
             for (uint32_t base = 0; base < total; base += 64u) {
                 const uint32_t idx = base + lane;
+                if (COUNT) { n_drain_it++; n_drain_act += total - base < 64u ? total - base : 64u; }
                 if (idx < total) {
                     const uint32_t code = tril[idx];
                     const uint32_t pos = (qh + (code >> 2)) % kLeafQ;
@@ -366,19 +411,41 @@ __global__ void __launch_bounds__(kExtBlock) k_extend(DScene S, DPaths P, Params
                     const unsigned long long cur = keyl[own];
                     const Tri T = load_tri(S.tris, tslot);
                     if (COUNT) wc.tris++;
-                    unsigned long long ck;
-                    if (tri_closest_key(T, f3(ro.x, ro.y, ro.z), f3(rd.x, rd.y, rd.z), tslot, cur, ck)) atomicMin(&keyl[own], ck);
+                    if (ANY) { if (cur == 0ull && tri_any_front(T, f3(ro.x, ro.y, ro.z), f3(rd.x, rd.y, rd.z), ro.w)) keyl[own] = 1ull; }
+                    else {
+                        unsigned long long ck;
+                        if (tri_closest_key(T, f3(ro.x, ro.y, ro.z), f3(rd.x, rd.y, rd.z), tslot, cur, ck)) atomicMin(&keyl[own], ck);
+                    }
                 }
             }
             __syncthreads();
             qh = (qh + m) % kLeafQ; nq -= m;
         }
+        PT_PHASE(ck_drain);
         // ================= after the drain: refresh pruning distances, finish meshes, steal
-        if (state == LS_TRAV || state == LS_THIEF) bt = __uint_as_float((uint32_t)(keyl[owner] >> 32));
+        if (state == LS_TRAV || state == LS_THIEF) {
+            const unsigned long long k = keyl[owner];
+            if (!ANY) bt = __uint_as_float((uint32_t)(k >> 32));
+            else if (k) { sp = sb; atomicSub(&nwork[owner], 1u); state = state == LS_TRAV ? LS_WAIT : LS_DONE; }   // blocked: abandon the walk
+        }
+        __syncthreads();
         if (state == LS_WAIT && nwork[lane] == 0u) {                    // every lane that walked for this ray is done, the queue is empty
             const unsigned long long k = keyl[lane];
-            if (k != (hit_key(best_t, 0u) & ~1ull)) { best_t = key_dist(k); best_inst = (int)ii; best_mesh = (int)mi; best_slot = (uint32_t)(k & 0xFFFFFFFFull) >> 1; }
-            mi++; state = LS_SETUP;
+            if (ANY) {
+                if (k) { P.vis[slot] = 1; state = LS_IDLE; }
+                else { rec++; state = LS_SETUP; }
+            } else {
+                if (k != (hit_key(best_t, 0u) & ~1ull)) {
+                    const float4 h1 = S.recs[(size_t)rec * kRecStride + 1];
+                    best_t = key_dist(k); best_inst = __float_as_int(h1.x); best_mesh = __float_as_int(h1.y); best_slot = (uint32_t)(k & 0xFFFFFFFFull) >> 1;
+                }
+                rec++; state = LS_SETUP;
+            }
+            if (state == LS_SETUP && rec >= (uint32_t)S.num_recs) {      // that was the last object: report now, the lane is idle
+                if (ANY) P.vis[slot] = 0;
+                else { P.ht[slot] = best_t; P.hinst[slot] = best_inst; P.hmesh[slot] = best_mesh; P.hslot[slot] = best_slot; }
+                state = LS_IDLE;
+            }
         }
         if (exhausted || prm.owner_lanes < 64u) {
             const unsigned long long idle = __ballot(state == LS_DONE);
@@ -398,16 +465,21 @@ __global__ void __launch_bounds__(kExtBlock) k_extend(DScene S, DPaths P, Params
                         owner = xfer[64 + r];
                         const float4 ro = rayl[2 * owner], rd = rayl[2 * owner + 1];
                         o = f3(ro.x, ro.y, ro.z); inv = f3(1.0f, 1.0f, 1.0f) / f3(rd.x, rd.y, rd.z); pabs = prune_abs(o);
-                        bt = __uint_as_float((uint32_t)(keyl[owner] >> 32));
+                        bt = ANY ? ro.w : __uint_as_float((uint32_t)(keyl[owner] >> 32));
                         PT_STK(0) = xfer[r]; sp = 1; sb = 0; state = LS_THIEF;
                     }
                 }
                 __syncthreads();
             }
         }
+        PT_PHASE(ck_rest);
     }
 #undef PT_STK
-    if (COUNT) { wave_add64(wc.nodes, &P.stat[3]); wave_add64(wc.tris, &P.stat[4]); }
+#undef PT_PHASE
+    if (COUNT) { wave_add64(wc.nodes, &P.stat[ANY ? 5 : 3]); wave_add64(wc.tris, &P.stat[ANY ? 6 : 4]);
+        if (!ANY && lane == 0) { atomicAdd(&P.stat[8], ck_setup); atomicAdd(&P.stat[9], ck_node); atomicAdd(&P.stat[10], ck_drain); atomicAdd(&P.stat[11], ck_rest);
+                                 atomicAdd(&P.stat[12], n_node_it); atomicAdd(&P.stat[13], n_node_act); atomicAdd(&P.stat[14], (n_drain_it << 32) | 0ull); } 
+        if (!ANY && lane == 0) atomicAdd(&P.stat[14], n_drain_act); }
 }
 
 // ---------------------------------------------------------------------- shade
@@ -421,7 +493,7 @@ __global__ void __launch_bounds__(kBlock) k_shade(DScene S, DCamera cam, DPaths 
     const size_t cap = P.cap;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < nround; i += gridDim.x * blockDim.x) {
         bool alive = false, shadow = false;
-        uint32_t slot = 0;
+        uint32_t slot = 0, vflags = 0;
         if (i < n) {
             slot = q ? q[i] : i;
             const uint32_t pixel = P.pix[slot], sample = P.smp[slot];
@@ -491,7 +563,7 @@ __global__ void __launch_bounds__(kBlock) k_shade(DScene S, DCamera cam, DPaths 
                             PT_SH(SH_TBX) = T.x; PT_SH(SH_TBY) = T.y; PT_SH(SH_TBZ) = T.z; PT_SH(SH_SELPDF) = selectPdf;
                             PT_SH(SH_FLAGS) = __uint_as_float(flags); PT_SH(SH_LIGHT) = __int_as_float(li);
 #undef PT_SH
-                            shadow = true;
+                            shadow = true; vflags = flags;
                         }
                     }
                     if (!flags) C = C + T * (f3(0, 0, 0) / selectPdf);   // throughput * black keeps NaN/Inf semantics
@@ -522,39 +594,37 @@ __global__ void __launch_bounds__(kBlock) k_shade(DScene S, DCamera cam, DPaths 
         }
         wave_enqueue(alive, slot, qnext, &P.counts[bounce + 1]);
         wave_enqueue(shadow, slot, P.squeue, &P.scounts[bounce]);
+        wave_enqueue(shadow && (vflags & 1u), slot * 2u, P.vqueue, &P.vcounts[bounce]);
+        wave_enqueue(shadow && (vflags & 2u), slot * 2u + 1u, P.vqueue, &P.vcounts[bounce]);
     }
 }
 
 // ---------------------------------------------------------------------- connect (NEE shadow ray + MIS)
 // LightComponent::SampleLi visibility, LightComponent::Pdf(wi), PowerHeuristic and the
-// `color += throughput * SampleLights(...)` of render.h:148.
-template <bool COUNT>
+// `color += throughput * SampleLights(...)` of render.h:148.  The visibility traces themselves were
+// done by k_trace<ANY>; this kernel combines their results.
 __global__ void __launch_bounds__(kBlock) k_connect(DScene S, DPaths P, uint32_t bounce) {
     const uint32_t n = P.scounts[bounce];
     const size_t cap = P.cap;
-    WorkCounters wc; wc.nodes = 0; wc.tris = 0;
-    __shared__ uint32_t sm_stack[kStackSize * kBlock];
-    uint32_t* lds = sm_stack + threadIdx.x;
     unsigned long long rays = 0;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const uint32_t slot = P.squeue[i];
         const float* sh = P.sh + slot;
 #define PT_SH(f) sh[(size_t)(f) * cap]
         const uint32_t flags = __float_as_uint(PT_SH(SH_FLAGS));
-        const DLight& L = S.lights[__float_as_int(PT_SH(SH_LIGHT))];
-        Ray r; r.p = f3(PT_SH(SH_OX), PT_SH(SH_OY), PT_SH(SH_OZ));
         F3 direct = f3(0, 0, 0);
-        F3 lp, ln;
         if (flags & 1u) {
-            r.d = f3(PT_SH(SH_W1X), PT_SH(SH_W1Y), PT_SH(SH_W1Z));
             rays++;
-            if (!light_vis_test<COUNT>(S, r, PT_SH(SH_TMAX1), L, lp, ln, wc, lds))
-                direct = direct + f3(PT_SH(SH_C1X), PT_SH(SH_C1Y), PT_SH(SH_C1Z));
+            if (!P.vis[2 * (size_t)slot]) direct = direct + f3(PT_SH(SH_C1X), PT_SH(SH_C1Y), PT_SH(SH_C1Z));
         }
         if (flags & 2u) {
-            r.d = f3(PT_SH(SH_W2X), PT_SH(SH_W2Y), PT_SH(SH_W2Z));
             rays++;
-            if (!light_vis_test<COUNT>(S, r, kBig, L, lp, ln, wc, lds)) {
+            if (!P.vis[2 * (size_t)slot + 1]) {
+                // the light's hit point / normal of LightVisTest's first sweep (raytracer.cpp:67-97), for LightComponent::Pdf(wi)
+                const DLight& L = S.lights[__float_as_int(PT_SH(SH_LIGHT))];
+                Ray r; r.p = f3(PT_SH(SH_OX), PT_SH(SH_OY), PT_SH(SH_OZ)); r.d = f3(PT_SH(SH_W2X), PT_SH(SH_W2Y), PT_SH(SH_W2Z));
+                F3 lp, ln;
+                light_hit_point(S, r, L, lp, ln);
                 const F3 hp = f3(PT_SH(SH_HPX), PT_SH(SH_HPY), PT_SH(SH_HPZ));
                 const float lightPdf = light_pdf(L, hp, lp, ln, len(lp - hp));
                 if (!(lightPdf <= 0.0f)) {
@@ -571,7 +641,6 @@ __global__ void __launch_bounds__(kBlock) k_connect(DScene S, DPaths P, uint32_t
 #undef PT_SH
     }
     wave_add64(rays, &P.stat[1]);
-    if (COUNT) { wave_add64(wc.nodes, &P.stat[5]); wave_add64(wc.tris, &P.stat[6]); }
 }
 
 // ---------------------------------------------------------------------- resolve
@@ -680,12 +749,12 @@ struct mi355pt_scene {
     mi355pt_camera camera{};
     std::vector<ptb::MeshTree> trees;
     DevBuf<DNodeXf> nodes; DevBuf<DInst> insts; DevBuf<DModel> models; DevBuf<DMesh> meshes;
-    DevBuf<float4> bvh_nodes, tris; DevBuf<uint32_t> faces; DevBuf<float> normals, uvw, tangents, bitangents;
+    DevBuf<float4> bvh_nodes, tris, recs; DevBuf<uint32_t> faces; DevBuf<float> normals, uvw, tangents, bitangents;
     DevBuf<mi355pt_material> materials; DevBuf<mi355pt_texmap> texmaps; DevBuf<DTexture> textures; DevBuf<DLight> lights;
     std::vector<void*> tex_data;
     uint64_t num_tris = 0, num_bvh_nodes = 0; int max_depth = 0;
     ~mi355pt_scene() {
-        nodes.release(); insts.release(); models.release(); meshes.release(); bvh_nodes.release(); tris.release(); faces.release();
+        nodes.release(); insts.release(); models.release(); meshes.release(); bvh_nodes.release(); tris.release(); recs.release(); faces.release();
         normals.release(); uvw.release(); tangents.release(); bitangents.release(); materials.release(); texmaps.release();
         textures.release(); lights.release();
         for (void* p : tex_data) (void)hipFree(p);
@@ -798,7 +867,7 @@ int mi355pt_scene_create(const mi355pt_scene_desc* desc, int32_t device, mi355pt
         if (s.node < 0 || (uint32_t)s.node >= desc->num_nodes || desc->nodes[s.node].object_kind != MI355PT_OBJ_PLANE)
             return fail(MI355PT_ERR_UNSUPPORTED, "lights must sit on Plane nodes (mesh lights are a later row)");
         DLight& d = lights[i];
-        d.node = s.node; memcpy(d.intensity, s.intensity, sizeof(d.intensity)); d.inst = inst_of_node[s.node]; d.pad0 = d.pad1 = 0;
+        d.node = s.node; memcpy(d.intensity, s.intensity, sizeof(d.intensity)); d.inst = inst_of_node[s.node]; d.rec = 0; d.pad1 = 0;
         const float* m = desc->nodes[s.node].local_to_world;       // Plane::Area, objects.cpp:496-503
         const H3 zero = h_m4mulp(m, H3{0, 0, 0}, 1.0f), wv = h_m4mulp(m, H3{2, 0, 0}, 1.0f), hv = h_m4mulp(m, H3{0, 2, 0}, 1.0f);
         d.area = h_len(H3{wv.x - zero.x, wv.y - zero.y, wv.z - zero.z}) * h_len(H3{hv.x - zero.x, hv.y - zero.y, hv.z - zero.z});
@@ -869,6 +938,39 @@ int mi355pt_scene_create(const mi355pt_scene_desc* desc, int32_t device, mi355pt
         }
     }
     sc->num_tris = tris.size() / 3; sc->num_bvh_nodes = bvh_nodes.size() / 4;
+    // ---- walk records (pt_scene.h), in the reference's visiting order
+    std::vector<float4> recs;
+    std::vector<int> inst_rec(insts.size() + 1, 0);
+    auto f_of = [](uint32_t u) { float f; memcpy(&f, &u, 4); return f; };
+    for (size_t ii = 0; ii < insts.size(); ii++) {
+        const DInst& in = insts[ii];
+        inst_rec[ii] = (int)(recs.size() / kRecStride);
+        const int nrec = in.kind == MI355PT_OBJ_MODEL ? models[in.model].num_meshes : 1;
+        for (int k = 0; k < nrec; k++) {
+            float4 R[kRecStride];
+            memset(R, 0, sizeof(R));
+            const uint32_t next = (uint32_t)(inst_rec[ii] + nrec);
+            R[0] = make_float4(f_of((uint32_t)in.kind), f_of((uint32_t)in.chain_len), f_of(next), f_of(k == 0 ? 1u : 0u));
+            if (in.kind == MI355PT_OBJ_MODEL) {
+                const DModel& mo = models[in.model]; const DMesh& M = meshes[mo.first_mesh + k];
+                R[1] = make_float4(f_of((uint32_t)ii), f_of((uint32_t)k), f_of(M.root_ref), f_of(M.root_cnt));
+                R[2] = make_float4(mo.aabb[0], mo.aabb[1], mo.aabb[2], mo.aabb[3]);
+                R[3] = make_float4(mo.aabb[4], mo.aabb[5], M.aabb[0], M.aabb[1]);
+                R[4] = make_float4(M.aabb[2], M.aabb[3], M.aabb[4], M.aabb[5]);
+                R[5] = make_float4(M.root_bound[0], M.root_bound[1], M.root_bound[2], M.root_bound[3]);
+                R[6] = make_float4(M.root_bound[4], M.root_bound[5], 0.0f, 0.0f);
+            } else R[1] = make_float4(f_of((uint32_t)ii), f_of(0u), f_of(0u), f_of(0u));
+            for (int l = 0; l < in.chain_len && l < kRecLevels; l++) {
+                const DNodeXf& nx = nodes[in.chain[l]];
+                R[7 + 3 * l] = make_float4(nx.itm[0], nx.itm[1], nx.itm[2], nx.itm[3]);
+                R[8 + 3 * l] = make_float4(nx.itm[4], nx.itm[5], nx.itm[6], nx.itm[7]);
+                R[9 + 3 * l] = make_float4(nx.itm[8], nx.pos[0], nx.pos[1], nx.pos[2]);
+            }
+            recs.insert(recs.end(), R, R + kRecStride);
+        }
+    }
+    inst_rec[insts.size()] = (int)(recs.size() / kRecStride);
+    for (auto& L : lights) L.rec = L.inst >= 0 ? inst_rec[L.inst] : 0;
     // ---- materials / textures
     std::vector<mi355pt_material> materials(desc->materials, desc->materials + desc->num_materials);
     std::vector<mi355pt_texmap> texmaps(desc->texmaps, desc->texmaps + desc->num_texmaps);
@@ -898,12 +1000,14 @@ int mi355pt_scene_create(const mi355pt_scene_desc* desc, int32_t device, mi355pt
     HIP_TRY(sc->nodes.upload(nodes)); HIP_TRY(sc->insts.upload(insts)); HIP_TRY(sc->models.upload(models)); HIP_TRY(sc->meshes.upload(meshes));
     HIP_TRY(sc->bvh_nodes.upload(bvh_nodes)); HIP_TRY(sc->tris.upload(tris)); HIP_TRY(sc->faces.upload(faces));
     HIP_TRY(sc->normals.upload(normals)); HIP_TRY(sc->uvw.upload(uvw)); HIP_TRY(sc->tangents.upload(tangents)); HIP_TRY(sc->bitangents.upload(bitangents));
+    HIP_TRY(sc->recs.upload(recs));
     HIP_TRY(sc->materials.upload(materials)); HIP_TRY(sc->texmaps.upload(texmaps)); HIP_TRY(sc->textures.upload(textures)); HIP_TRY(sc->lights.upload(lights));
     DScene& d = sc->d;
     d.nodes = sc->nodes.p; d.num_nodes = (int)nodes.size(); d.insts = sc->insts.p; d.num_insts = (int)insts.size();
     d.models = sc->models.p; d.meshes = sc->meshes.p; d.bvh_nodes = sc->bvh_nodes.p; d.tris = sc->tris.p; d.faces = sc->faces.p;
     d.normals = sc->normals.p; d.uvw = sc->uvw.p; d.tangents = sc->tangents.p; d.bitangents = sc->bitangents.p;
     d.materials = sc->materials.p; d.texmaps = sc->texmaps.p; d.textures = sc->textures.p; d.lights = sc->lights.p; d.num_lights = (int)lights.size();
+    d.recs = sc->recs.p; d.num_recs = (int)(recs.size() / kRecStride);
     memcpy(d.env_color, desc->env_color, sizeof(d.env_color)); d.env_map = desc->env_map;
     for (int i = 0; i < 32; i++) {      // Texture::Sample tap offsets (scene.h:169-175), host libm like the reference
         auto halton = [](int index, int base) { float r = 0; float f = 1.0f / (float)base; for (int k = index; k > 0; k /= base) { r += f * (k % base); f /= (float)base; } return r; };
@@ -972,6 +1076,8 @@ int mi355pt_render_create(mi355pt_scene* scene, const mi355pt_render_params* par
     HIP_TRY(dalloc((void**)&P.queue[0], cap * 4)); HIP_TRY(dalloc((void**)&P.queue[1], cap * 4)); HIP_TRY(dalloc((void**)&P.squeue, cap * 4));
     const size_t nb = params->max_bounces + 2;
     HIP_TRY(dalloc((void**)&P.counts, nb * 4)); HIP_TRY(dalloc((void**)&P.scounts, nb * 4)); HIP_TRY(dalloc((void**)&P.work, nb * 4));
+    HIP_TRY(dalloc((void**)&P.vqueue, cap * 8)); HIP_TRY(dalloc((void**)&P.vcounts, nb * 4)); HIP_TRY(dalloc((void**)&P.vwork, nb * 4));
+    HIP_TRY(dalloc((void**)&P.vis, cap * 2));
     HIP_TRY(dalloc((void**)&P.stat, 16 * sizeof(unsigned long long)));
     HIP_TRY(hipMemsetAsync(P.stat, 0, 16 * sizeof(unsigned long long), r->stream));
     HIP_TRY(dalloc((void**)&r->mean, npix * 12)); HIP_TRY(dalloc((void**)&r->cnt, npix * 4)); HIP_TRY(dalloc((void**)&r->rgb8, npix * 3));
@@ -987,7 +1093,7 @@ int mi355pt_render_create(mi355pt_scene* scene, const mi355pt_render_params* par
         r->stack_entries = (uint32_t)entries;
         r->extend_lds = extend_lds_bytes((uint32_t)entries);
         int waves = 0;
-        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&waves, k_extend<false>, kExtBlock, r->extend_lds));
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&waves, k_trace<false, false>, kExtBlock, r->extend_lds));
         if (const char* e = getenv("MI355PT_EXTEND_WAVES_PER_CU")) waves = std::min(waves, std::max(1, atoi(e)));
         r->extend_grid = prop.multiProcessorCount * std::max(1, waves);
     }
@@ -1044,21 +1150,24 @@ int run_paths(mi355pt_render* r, uint32_t n, uint32_t jitter = 1, uint32_t only_
     HIP_TRY(hipMemsetAsync(P.counts, 0, nb * 4, r->stream));
     HIP_TRY(hipMemsetAsync(P.scounts, 0, nb * 4, r->stream));
     HIP_TRY(hipMemsetAsync(P.work, 0, nb * 4, r->stream));
+    HIP_TRY(hipMemsetAsync(P.vcounts, 0, nb * 4, r->stream));
+    HIP_TRY(hipMemsetAsync(P.vwork, 0, nb * 4, r->stream));
     const int g = grid_for(r, n);
     const int ge = (int)std::max<size_t>(1, std::min<size_t>(((size_t)n + 63) / 64, (size_t)r->extend_grid));     // persistent: resident waves only
     if (jitter != 2) hipLaunchKernelGGL(k_raygen, dim3(g), dim3(kBlock), 0, r->stream, r->cam, P, prm, n, jitter);
     for (uint32_t b = 0; b < (only_extend ? 1u : p.max_bounces); b++) {
         ev_begin(r, 0);
-        if (r->count_work) hipLaunchKernelGGL(k_extend<true>, dim3(ge), dim3(kExtBlock), r->extend_lds, r->stream, S, P, prm, b, n);
-        else hipLaunchKernelGGL(k_extend<false>, dim3(ge), dim3(kExtBlock), r->extend_lds, r->stream, S, P, prm, b, n);
+        if (r->count_work) hipLaunchKernelGGL((k_trace<false, true>), dim3(ge), dim3(kExtBlock), r->extend_lds, r->stream, S, P, prm, b, n);
+        else hipLaunchKernelGGL((k_trace<false, false>), dim3(ge), dim3(kExtBlock), r->extend_lds, r->stream, S, P, prm, b, n);
         ev_end(r);
         if (only_extend) break;
         ev_begin(r, 1);
         hipLaunchKernelGGL(k_shade, dim3(g), dim3(kBlock), 0, r->stream, S, r->cam, P, prm, b, n);
         ev_end(r);
         ev_begin(r, 2);
-        if (r->count_work) hipLaunchKernelGGL(k_connect<true>, dim3(g), dim3(kBlock), 0, r->stream, S, P, b);
-        else hipLaunchKernelGGL(k_connect<false>, dim3(g), dim3(kBlock), 0, r->stream, S, P, b);
+        if (r->count_work) hipLaunchKernelGGL((k_trace<true, true>), dim3(ge), dim3(kExtBlock), r->extend_lds, r->stream, S, P, prm, b, n);
+        else hipLaunchKernelGGL((k_trace<true, false>), dim3(ge), dim3(kExtBlock), r->extend_lds, r->stream, S, P, prm, b, n);
+        hipLaunchKernelGGL(k_connect, dim3(g), dim3(kBlock), 0, r->stream, S, P, b);
         ev_end(r);
     }
     if (!only_extend) hipLaunchKernelGGL(k_stats, dim3(1), dim3(64), 0, r->stream, P, n, p.max_bounces);
@@ -1103,7 +1212,7 @@ int mi355pt_render_sync(mi355pt_render* r) {
     HIP_TRY(hipStreamSynchronize(r->stream));
     drain_events(r);
     unsigned long long guard = 0;
-    HIP_TRY(hipMemcpy(&guard, r->P.stat + 15, sizeof(guard), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(&guard, r->P.stat + 7, sizeof(guard), hipMemcpyDeviceToHost));
     if (guard) return fail(MI355PT_ERR_HIP, "k_extend gave up: a wave exceeded its pass limit (results are incomplete)");
     return MI355PT_OK;
 }
@@ -1223,7 +1332,7 @@ int mi355pt_render_stats(mi355pt_render* r, mi355pt_stats* st) {
     HIP_TRY(hipMemcpy(h, r->P.stat, sizeof(h), hipMemcpyDeviceToHost));
     for (int i = 0; i < 8; i++) st->debug[i] = h[8 + i];
     st->closest_rays = h[0]; st->shadow_rays = h[1]; st->samples = h[2]; st->bvh_node_visits = h[3]; st->bvh_tri_tests = h[4];
-    st->shadow_node_visits = h[5]; st->shadow_tri_tests = h[6]; st->max_nodes_per_ray = h[7];
+    st->shadow_node_visits = h[5]; st->shadow_tri_tests = h[6]; st->max_nodes_per_ray = 0;
     st->extend_ms = r->ms[0]; st->shade_ms = r->ms[1]; st->connect_ms = r->ms[2]; st->other_ms = r->ms[3];
     st->extend_launches = r->extend_launches;
     return MI355PT_OK;

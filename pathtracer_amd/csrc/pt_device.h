@@ -146,6 +146,22 @@ PT_DEV Ray to_inst(const DScene& S, const DInst& in, Ray r) {
     return r;
 }
 
+// Ray into the space of a walk record's object (pt_scene.h): ToNodeCoords level by level, root first.
+PT_DEV Ray rec_ray(const DScene& S, const float4* R, uint32_t chain_len, uint32_t inst, Ray r) {
+    for (uint32_t l = 0; l < chain_len; l++) {
+        if (l < (uint32_t)kRecLevels) {
+            const float4 a = R[7 + 3 * l], b = R[8 + 3 * l], c = R[9 + 3 * l];
+            const float itm[9] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x};
+            const F3 pos = f3(c.y, c.z, c.w);
+            Ray o;
+            o.p = m3mul(itm, r.p - pos);
+            o.d = m3mul(itm, (r.p + r.d) - pos) - o.p;
+            r = o;
+        } else r = to_node(S.nodes[S.insts[inst].chain[l]], r);
+    }
+    return r;
+}
+
 // ------------------------------------------------------------------ slab test (bvh.h:88-129, scene.cpp:3-40)
 // inv = 1/dir is computed once per (ray, instance): same values as the reference's per-call division.
 PT_DEV bool slab(const float* b, F3 p, F3 inv, float& tnear) {
@@ -286,94 +302,13 @@ PT_DEV bool tri_any_front(const Tri& T, F3 o, F3 d, float bound) {
     return a0 > 0.0f && a1 > 0.0f && a2 > 0.0f;
 }
 
-// ------------------------------------------------------------------ BVH traversal
-// Ordered, pruned walk over the flattened tree (layout: bvh_build.h).  Reference semantics kept:
-// a node's bound is tested only when the node is internal; leaf faces are all tested; the result
-// is the minimum in (t, slot) order == the reference's exhaustive recursion with its tie rules
-// (src/model.cpp:4-163).  Pruning uses the slab entry distance against the running best.
-constexpr int kStackSize = 48;        // entries per lane; host checks tree depth + 4 <= kStackSize
-constexpr int kTravBlock = 256;       // threads per block of every kernel that traverses
-constexpr uint32_t kLeafFlag = 0x80000000u, kLeafSlotMask = 0x07FFFFFFu;   // leaf entry: flag | count<<27 | first slot
-constexpr uint32_t kInternal = 0xFFFFFFFFu, kChain = 0xFFFFFFFEu;         // count words of a node record (bvh_build.h)
+// ------------------------------------------------------------------ BVH encoding (bvh_build.h)
+constexpr int kStackSize = 48;        // stack entries per lane; the host checks tree depth + 4 <= kStackSize
+constexpr int kTravBlock = 256;       // threads per block of the streaming kernels
+constexpr uint32_t kLeafFlag = 0x80000000u, kLeafSlotMask = 0x07FFFFFFu;   // leaf item: flag | (count - 1) << 27 | first slot
+constexpr uint32_t kInternal = 0xFFFFFFFFu, kChain = 0xFFFFFFFEu;         // count words of a node record
 struct WorkCounters { uint32_t nodes, tris; };
-
-// Traversal stack: node / leaf references live in LDS (one dword per entry, entry e of lane l at
-// lds[e * kTravBlock + l]: consecutive lanes hit consecutive banks, conflict-free), the entry
-// distances used for the pop-time cull live in a private array that is read in the shadow of the
-// node fetch (the fetch is issued first).  The loop is "while-while": every lane walks internal
-// nodes until it holds a leaf, then the wave tests triangles together, so the expensive
-// bit-exact triangle test runs with most lanes active.
-template <bool ANY, bool COUNT>
-PT_DEV bool traverse_mesh(const DScene& S, const DMesh& M, F3 o, F3 d, F3 inv, int side, float& bt, uint32_t& bslot, WorkCounters& wc,
-                          uint32_t* lds) {
-    // ANY: bt is the (fixed) bound; returns true on the first accepted front-face hit.
-    // !ANY: (bt, bslot) updated; returns true if it changed.
-#define PT_STK(i) lds[(i) * kTravBlock]
-    bool changed = false;
-    float stack_t[kStackSize];
-    const float pabs = prune_abs(o);
-    int sp = 0;
-    auto push_leaf = [&](uint32_t first, uint32_t cnt) {
-        while (cnt) {
-            const uint32_t c = cnt > 15u ? 15u : cnt;
-            if (sp < kStackSize) { PT_STK(sp) = kLeafFlag | (c << 27) | first; sp++; }
-            first += c; cnt -= c;
-        }
-    };
-    if (M.root_cnt == kInternal) {
-        float tn;
-        if (COUNT) wc.nodes++;
-        if (!slab(M.root_bound, o, inv, tn)) return false;
-        PT_STK(0) = M.root_ref; stack_t[0] = -kBig; sp = 1;
-    } else if (M.root_cnt == kChain) {
-        PT_STK(0) = M.root_ref; stack_t[0] = -kBig; sp = 1;
-    } else {
-        push_leaf(M.root_ref, M.root_cnt);
-    }
-    for (;;) {
-        uint32_t lf = 0, lc = 0;
-        while (sp > 0) {
-            sp--;
-            const uint32_t e = PT_STK(sp);
-            if (e & kLeafFlag) { lf = e & kLeafSlotMask; lc = (e >> 27) & 15u; break; }
-            const float4* np = S.bvh_nodes + 4 * (size_t)e;
-            const float4 w0 = np[0], w1 = np[1], w2 = np[2], w3 = np[3];
-            if (beyond(stack_t[sp], bt, pabs)) continue;          // pruned by a hit found since the push
-            if (COUNT) wc.nodes++;
-            const float lb[6] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y};
-            const float rb[6] = {w1.z, w1.w, w2.x, w2.y, w2.z, w2.w};
-            const uint32_t lref = __float_as_uint(w3.x), rref = __float_as_uint(w3.y), lcnt = __float_as_uint(w3.z), rcnt = __float_as_uint(w3.w);
-            float tl = -kBig, tr = -kBig;
-            bool hl = false, hr = false;
-            if (lcnt == kInternal) { hl = slab(lb, o, inv, tl); if (beyond(tl, bt, pabs)) hl = false; }
-            else if (lcnt == kChain) hl = true;                   // chain records carry no bound (bvh_build.h)
-            if (rcnt == kInternal) { hr = slab(rb, o, inv, tr); if (beyond(tr, bt, pabs)) hr = false; }
-            else if (rcnt == kChain) hr = true;
-            // internal children: far first, so the near one is popped first; leaves last, so they are
-            // popped before either (cheap, and they shrink the pruning distance early)
-            const bool left_first = !(tr < tl);
-            if (hl && hr) {
-                if (sp + 2 <= kStackSize) {
-                    if (left_first) { PT_STK(sp) = rref; stack_t[sp] = tr; sp++; PT_STK(sp) = lref; stack_t[sp] = tl; sp++; }
-                    else { PT_STK(sp) = lref; stack_t[sp] = tl; sp++; PT_STK(sp) = rref; stack_t[sp] = tr; sp++; }
-                }
-            } else if (hl) { if (sp < kStackSize) { PT_STK(sp) = lref; stack_t[sp] = tl; sp++; } }
-            else if (hr) { if (sp < kStackSize) { PT_STK(sp) = rref; stack_t[sp] = tr; sp++; } }
-            if (lcnt < kChain) push_leaf(lref, lcnt);
-            if (rcnt < kChain) push_leaf(rref, rcnt);
-        }
-        if (lc == 0) { if (sp == 0) break; else continue; }
-        for (uint32_t k = 0; k < lc; k++) {
-            const uint32_t slot = lf + k;
-            const Tri T = load_tri(S.tris, slot);
-            if (COUNT) wc.tris++;
-            if (ANY) { if (tri_any_front(T, o, d, bt)) return true; }
-            else changed |= tri_closest(T, o, d, side, slot, bt, bslot);
-        }
-    }
-#undef PT_STK
-    return ANY ? false : changed;
-}
+struct HitRec { float t; int inst; int mesh; uint32_t slot; };     // closest-hit record of one path
 
 // ------------------------------------------------------------------ plane (objects.cpp:560-614)
 PT_DEV bool plane_hit(F3 o, F3 d, int side, float& t, bool& front, F3& P) {
@@ -389,41 +324,6 @@ PT_DEV bool plane_hit(F3 o, F3 d, int side, float& t, bool& front, F3& P) {
     if (side == SIDE_BACK && f) return false;
     t = tt; front = f; P = p;
     return true;
-}
-
-// ------------------------------------------------------------------ closest hit over the scene
-// TraceNode (raytracer.cpp:189-258) over the instance table: instances are in the reference's
-// depth-first order and a later instance must be strictly closer to win.
-struct HitRec { float t; int inst; int mesh; uint32_t slot; };
-
-template <bool COUNT>
-PT_DEV HitRec trace_closest(const DScene& S, const Ray& wr, WorkCounters& wc, uint32_t* lds) {
-    HitRec best; best.t = kBig; best.inst = -1; best.mesh = -1; best.slot = 0;
-    for (int ii = 0; ii < S.num_insts; ii++) {
-        const DInst& in = S.insts[ii];
-        const Ray lr = to_inst(S, in, wr);
-        if (in.kind == MI355PT_OBJ_PLANE) {
-            float t; bool front; F3 P;
-            if (plane_hit(lr.p, lr.d, SIDE_BOTH, t, front, P) && t < best.t) { best.t = t; best.inst = ii; best.mesh = -1; best.slot = 0; }
-        } else if (in.kind == MI355PT_OBJ_MODEL) {
-            const DModel& mo = S.models[in.model];
-            const F3 inv = f3(1.0f, 1.0f, 1.0f) / lr.d;
-            float tn;
-            if (!slab(mo.aabb, lr.p, inv, tn)) continue;
-            for (int mi = 0; mi < mo.num_meshes; mi++) {
-                const DMesh& M = S.meshes[mo.first_mesh + mi];
-                if (!slab(M.aabb, lr.p, inv, tn)) continue;
-                // Start from the global best with bslot = 0: no slot is < 0, so a candidate with
-                // t == best.t loses (the earlier object wins ties, raytracer.cpp:208,238 / model.cpp:237)
-                // and only a strictly closer one replaces it.
-                float bt = best.t; uint32_t bslot = 0;
-                bool ch;
-                ch = traverse_mesh<false, COUNT>(S, M, lr.p, lr.d, inv, SIDE_BOTH, bt, bslot, wc, lds);
-                if (ch) { best.t = bt; best.inst = ii; best.mesh = mi; best.slot = bslot; }
-            }
-        }
-    }
-    return best;
 }
 
 }  // namespace ptd

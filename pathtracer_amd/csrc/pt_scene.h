@@ -27,11 +27,21 @@ struct DMesh {
     uint32_t has_tangents, pad;
 };
 struct DTexture { int kind, width, height, pad; const void* data; float c1[3], c2[3]; };
-struct DLight { int node; float intensity[3]; float area; int inst; int pad0, pad1; };
+struct DLight { int node; float intensity[3]; float area; int inst; int rec; int pad1; };      // rec: the light object's walk record
 struct DCamera {
     float pos[3], up[3], front[3], right[3];
     float plane_h, plane_w, texel_w, texel_h, focaldist, dof;
 };
+
+// Walk records: what TraceNode / LightVisTest visit, in the reference's order (depth-first over the scene graph,
+// then over a model's meshes), one record per Plane and one per (Model, mesh) pair, each holding everything the
+// per-ray set-up needs in one contiguous read: the node chain's transforms, the model / mesh / root bounds and the
+// BVH root.  Layout in float4 units (kRecStride per record):
+//   [0] kind, chain_len, first record of the NEXT object, flags (bit 0: first mesh of its model)    (uints)
+//   [1] instance index, mesh index, root_ref, root_cnt                                               (uints)
+//   [2..4] model aabb (6), mesh aabb (6)      [5..6] root bound (6), 2 pad
+//   [7 + 3 l ..] level l of the chain, root first: itm (9), pos (3); levels >= kRecLevels are read from nodes[]
+constexpr int kRecLevels = 4, kRecStride = 7 + 3 * kRecLevels + 1;
 
 struct DScene {
     const DNodeXf*  nodes;      int num_nodes;
@@ -49,6 +59,7 @@ struct DScene {
     const mi355pt_texmap*   texmaps;
     const DTexture* textures;
     const DLight*   lights;     int num_lights;
+    const float4*   recs;       int num_recs;
     float env_color[3];         int env_map;
     float filter_taps[64];           // (x, y) of the 32 elliptic filter taps, scene.h:169-181
 };

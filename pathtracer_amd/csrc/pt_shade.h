@@ -432,45 +432,20 @@ PT_DEV float light_pdf(const DLight& L, F3 hitp, F3 sp, F3 sn, float distance) {
     return d2 / (L.area * c);
 }
 
-// LightVisTest (raytracer.cpp:67-152).  Returns true when BLOCKED; on "not blocked" lp/ln hold the
-// light hit point / normal in world space.
-template <bool COUNT>
-PT_DEV bool light_vis_test(const DScene& S, const Ray& wr, float tmax, const DLight& L, F3& lp, F3& ln, WorkCounters& wc, uint32_t* lds) {
-    // (1) the light's own object, both sides
+// First sweep of LightVisTest (raytracer.cpp:67-97): the light's own object, both sides.  Returns true for a
+// front-side hit; lp / ln = the hit point / normal in world space.  (The second sweep, over every other object,
+// is k_trace<ANY> in mi355pt.hip.)
+PT_DEV bool light_hit_point(const DScene& S, const Ray& wr, const DLight& L, F3& lp, F3& ln) {
     const DInst& li = S.insts[L.inst];
     const Ray lr = to_inst(S, li, wr);
     float lz; bool front; F3 P;
-    if (!plane_hit(lr.p, lr.d, SIDE_BOTH, lz, front, P)) return true;
-    {
-        Surf h; h.p = P; h.N = front ? f3(0.0f, 0.0f, 1.0f) : -1.0f * f3(0.0f, 0.0f, 1.0f);
-        h.T = f3(1.0f, 0.0f, 0.0f); h.B = f3(0.0f, 1.0f, 0.0f);
-        surf_to_world(S, li, h);
-        lp = h.p; ln = h.N;
-    }
-    if (!front) return true;
-    // (2) every other object: a front-face hit nearer than tmax and the light blocks
-    const float bound = tmax < lz ? tmax : lz;       // z < tmax && z < lightZ
-    for (int ii = 0; ii < S.num_insts; ii++) {
-        if (ii == L.inst) continue;
-        const DInst& in = S.insts[ii];
-        const Ray r = to_inst(S, in, wr);
-        if (in.kind == MI355PT_OBJ_PLANE) {
-            float t; bool f; F3 Q;
-            if (plane_hit(r.p, r.d, SIDE_FRONT, t, f, Q) && t < tmax && t < lz) return true;
-        } else if (in.kind == MI355PT_OBJ_MODEL) {
-            const DModel& mo = S.models[in.model];
-            const F3 inv = f3(1.0f, 1.0f, 1.0f) / r.d;
-            float tn;
-            if (!slab(mo.aabb, r.p, inv, tn)) continue;
-            for (int mi = 0; mi < mo.num_meshes; mi++) {
-                const DMesh& M = S.meshes[mo.first_mesh + mi];
-                if (!slab(M.aabb, r.p, inv, tn)) continue;
-                float b = bound; uint32_t dummy = 0;
-                if (traverse_mesh<true, COUNT>(S, M, r.p, r.d, inv, SIDE_FRONT, b, dummy, wc, lds)) return true;
-            }
-        }
-    }
-    return false;
+    lp = ln = f3(0, 0, 0);
+    if (!plane_hit(lr.p, lr.d, SIDE_BOTH, lz, front, P)) return false;
+    Surf h; h.p = P; h.N = front ? f3(0.0f, 0.0f, 1.0f) : -1.0f * f3(0.0f, 0.0f, 1.0f);
+    h.T = f3(1.0f, 0.0f, 0.0f); h.B = f3(0.0f, 1.0f, 0.0f);
+    surf_to_world(S, li, h);
+    lp = h.p; ln = h.N;
+    return front;
 }
 
 // ------------------------------------------------------------------ tone mapping (tonemapping.h:14-42)

@@ -13,11 +13,14 @@ for mb in (1, 2, 3, 4, 6):
     pt.render(1)
     pt.reset_stats(); pt.set_profiling(True, False); pt.render(1); t = pt.stats()
     pt.reset_stats(); pt.set_profiling(False, True); pt.render(1); c = pt.stats()
-    cur = dict(rays=c["closest_rays"], nodes=c["bvh_node_visits"], tris=c["bvh_tri_tests"], ext=t["extend_ms"], sh=t["shade_ms"], co=t["connect_ms"],
+    dbg = c["debug"]
+    cur = dict(cs=dbg[0], cn=dbg[1], cd=dbg[2], cr=dbg[3], nit=dbg[4], nact=dbg[5], dit=dbg[6] >> 32, dact=dbg[6] & 0xFFFFFFFF, rays=c["closest_rays"], nodes=c["bvh_node_visits"], tris=c["bvh_tri_tests"], ext=t["extend_ms"], sh=t["shade_ms"], co=t["connect_ms"],
                srays=c["shadow_rays"], snodes=c["shadow_node_visits"], stris=c["shadow_tri_tests"])
     d = cur if prev is None else {k: cur[k] - prev[k] for k in cur}
     print(f"bounces<{mb}: closest rays {d['rays']:>9d} nodes/ray {d['nodes']/max(d['rays'],1):6.1f} tris/ray {d['tris']/max(d['rays'],1):5.1f} extend {d['ext']:7.2f} ms "
           f"({d['rays']/max(d['ext'],1e-9)/1e3:7.1f} Mrays/s) | shadow rays {d['srays']:>9d} nodes/ray {d['snodes']/max(d['srays'],1):6.1f} tris/ray {d['stris']/max(d['srays'],1):5.1f} "
           f"connect {d['co']:6.2f} ms shade {d['sh']:6.2f} ms", flush=True)
+    tot = max(d['cs'] + d['cn'] + d['cd'] + d['cr'], 1)
+    print(f"      extend wave cycles: setup {100*d['cs']/tot:4.1f} %  node {100*d['cn']/tot:4.1f} %  drain {100*d['cd']/tot:4.1f} %  rest {100*d['cr']/tot:4.1f} % | node iters {d['nit']} lanes/iter {d['nact']/max(d['nit'],1):4.1f} cycles/iter {d['cn']/max(d['nit'],1):5.0f} | drain iters {d['dit']} lanes/iter {d['dact']/max(d['dit'],1):4.1f} cycles/iter {d['cd']/max(d['dit'],1):5.0f}", flush=True)
     prev = cur
     pt.close_render()
