@@ -28,18 +28,25 @@
 using namespace ptd;
 
 // ====================================================================== path state
-constexpr int kShFields = 26;
-enum ShField { SH_OX = 0, SH_OY, SH_OZ, SH_W1X, SH_W1Y, SH_W1Z, SH_TMAX1, SH_C1X, SH_C1Y, SH_C1Z,
-               SH_W2X, SH_W2Y, SH_W2Z, SH_A2X, SH_A2Y, SH_A2Z, SH_PDFB, SH_HPX, SH_HPY, SH_HPZ,
-               SH_TBX, SH_TBY, SH_TBZ, SH_SELPDF, SH_FLAGS, SH_LIGHT };
+// Path state is array-of-structures in 16-byte pieces: from bounce 1 on the paths of a wave are scattered
+// over the pool (compacted queues), so one ray / hit / shadow record must be one or two aligned 16-byte accesses,
+// not six 4-byte ones in six cache lines.
+enum { SHV_O = 0,      // origin of both visibility rays (hit point + N * bias), w = distance to the light sample
+       SHV_W1,         // direction to the light sample, w = light index (int bits)
+       SHV_W2,         // direction of the MIS BRDF sample, w = light index again (each visibility item reads O and one W)
+       SHV_C1,         // contribution of the light sample if visible, w = pdf of the BRDF sample
+       SHV_A2,         // NdotL * f * Le of the BRDF sample, w = 1 / numLights
+       SHV_HP,         // the shaded point, w = flags (bit 0: light sample queued, bit 1: BRDF sample queued)
+       SHV_TB,         // throughput at this vertex
+       kShVec };
 
 struct DPaths {
     uint32_t  cap;
-    uint32_t *pix, *smp, *draw;
-    float    *ray;        // 6 x cap : origin, direction of the ray to trace next (bounce > 0)
-    float    *T, *C;      // 3 x cap each: throughput, accumulated radiance
-    float    *ht; int *hinst, *hmesh; uint32_t *hslot;       // closest-hit record
-    float    *sh;         // kShFields x cap: NEE / MIS shadow work of the current bounce
+    uint4    *id;         // (pixel, sample index, next RNG draw, -)
+    float4   *ray;        // 2 x cap: (origin, -), (direction, -) of the ray to trace next
+    float4   *T, *C;      // throughput, accumulated radiance
+    uint4    *hit;        // closest-hit record: (t bits, instance, mesh, triangle slot)
+    float4   *sh;         // kShVec x cap, record-major: NEE / MIS work of the current bounce
     uint32_t *queue[2];   // path-slot indices, ping-pong
     uint32_t *squeue;     // slots with shadow work this bounce
     uint32_t *counts;     // [b] = #paths entering bounce b (b >= 1)
@@ -48,13 +55,21 @@ struct DPaths {
     uint32_t *vcounts;    // [b] = #visibility items at bounce b
     uint32_t *vwork;      // [b] = next vqueue index to hand out in k_trace<ANY>
     uint8_t  *vis;        // [2 x cap] 1 = blocked, per visibility item
-    uint32_t *work;       // [b] = next queue index to hand out in k_extend of bounce b (persistent refill)
-    unsigned long long *stat;   // [0] closest rays [1] shadow rays [2] samples [3,4] extend node visits / tri tests [5,6] connect ditto
+    uint32_t *work;       // [b] = next queue index to hand out in k_trace<closest> of bounce b (persistent refill)
+    unsigned long long *stat;   // [0] closest rays [1] shadow rays [2] samples [3,4] extend node visits / tri tests [5,6] visibility ditto [7] guard
 };
 struct Params { uint32_t seed, width, height, max_bounces, rr_start, stack_entries, node_lanes, owner_lanes; };
 
-#define PT_LD3(arr, cap, i) f3((arr)[(i)], (arr)[(size_t)(cap) + (i)], (arr)[2 * (size_t)(cap) + (i)])
-#define PT_ST3(arr, cap, i, v) do { (arr)[(i)] = (v).x; (arr)[(size_t)(cap) + (i)] = (v).y; (arr)[2 * (size_t)(cap) + (i)] = (v).z; } while (0)
+__device__ __forceinline__ F3 xyz(float4 v) { return f3(v.x, v.y, v.z); }
+__device__ __forceinline__ float4 f4(F3 v, float w) { return make_float4(v.x, v.y, v.z, w); }
+__device__ __forceinline__ void store_hit(const DPaths& P, uint32_t slot, float t, int inst, int mesh, uint32_t tslot) {
+    P.hit[slot] = make_uint4(__float_as_uint(t), (uint32_t)inst, (uint32_t)mesh, tslot);
+}
+__device__ __forceinline__ HitRec load_hit(const DPaths& P, uint32_t slot) {
+    const uint4 v = P.hit[slot];
+    HitRec h; h.t = __uint_as_float(v.x); h.inst = (int)v.y; h.mesh = (int)v.z; h.slot = v.w;
+    return h;
+}
 
 constexpr int kBlock = kTravBlock;
 
@@ -94,9 +109,8 @@ __global__ void __launch_bounds__(kBlock) k_init(DPaths P, Params prm, uint32_t 
             pixel = pix_base + (i - s * npix_chunk);
             sample = sample_offset + (cnt[pixel] + s) * sample_stride;
         }
-        P.pix[i] = pixel; P.smp[i] = sample; P.draw[i] = 2;     // draws 0,1 = lens (utils.cpp:70,73)
-        const F3 one = f3(1.0f, 1.0f, 1.0f), zero = f3(0.0f, 0.0f, 0.0f);
-        PT_ST3(P.T, P.cap, i, one); PT_ST3(P.C, P.cap, i, zero);
+        P.id[i] = make_uint4(pixel, sample, 2u, 0u);            // draws 0,1 = lens (utils.cpp:70,73)
+        P.T[i] = make_float4(1.0f, 1.0f, 1.0f, 0.0f); P.C[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     }
 }
 
@@ -105,12 +119,11 @@ __global__ void __launch_bounds__(kBlock) k_init(DPaths P, Params prm, uint32_t 
 // raytracer.cpp:272-316).  The main ray goes to P.ray so that k_extend reads every bounce the same way;
 // k_shade recomputes the two differential rays for the primary hit only.
 __global__ void __launch_bounds__(kBlock) k_raygen(DCamera cam, DPaths P, Params prm, uint32_t n, uint32_t jitter) {
-    const size_t cap = P.cap;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         Ray r; F3 rd, td;
-        camera_rays(cam, prm.seed, P.pix[i], P.smp[i], prm.width, jitter != 0, r, rd, td);
-        P.ray[i] = r.p.x; P.ray[cap + i] = r.p.y; P.ray[2 * cap + i] = r.p.z;
-        P.ray[3 * cap + i] = r.d.x; P.ray[4 * cap + i] = r.d.y; P.ray[5 * cap + i] = r.d.z;
+        const uint4 id = P.id[i];
+        camera_rays(cam, prm.seed, id.x, id.y, prm.width, jitter != 0, r, rd, td);
+        P.ray[2 * (size_t)i] = f4(r.p, 0.0f); P.ray[2 * (size_t)i + 1] = f4(r.d, 0.0f);
     }
 }
 
@@ -166,7 +179,6 @@ __global__ void __launch_bounds__(kExtBlock) k_trace(DScene S, DPaths P, Params 
     const uint32_t n = ANY ? P.vcounts[bounce] : (bounce == 0 ? n0 : P.counts[bounce]);
     const uint32_t* q = ANY ? P.vqueue : (bounce == 0 ? nullptr : P.queue[bounce & 1]);
     uint32_t* work = ANY ? &P.vwork[bounce] : &P.work[bounce];
-    const size_t cap = P.cap;
     extern __shared__ uint32_t sm[];
     const uint32_t lane = threadIdx.x;
     const unsigned long long lt = (1ull << lane) - 1ull;
@@ -187,13 +199,10 @@ __global__ void __launch_bounds__(kExtBlock) k_trace(DScene S, DPaths P, Params 
     float bound = 0.0f; uint32_t linst = 0;                                                // any: distance bound, the light's object
     auto load_world = [&](uint32_t it, Ray& wr) {                // closest: `it` is a path slot; any: slot * 2 + which
         if (!ANY) {
-            wr.p = f3(P.ray[it], P.ray[cap + it], P.ray[2 * cap + it]);
-            wr.d = f3(P.ray[3 * cap + it], P.ray[4 * cap + it], P.ray[5 * cap + it]);
+            wr.p = xyz(P.ray[2 * (size_t)it]); wr.d = xyz(P.ray[2 * (size_t)it + 1]);
         } else {
-            const float* sh = P.sh + (it >> 1);
-            wr.p = f3(sh[(size_t)SH_OX * cap], sh[(size_t)SH_OY * cap], sh[(size_t)SH_OZ * cap]);
-            wr.d = (it & 1u) ? f3(sh[(size_t)SH_W2X * cap], sh[(size_t)SH_W2Y * cap], sh[(size_t)SH_W2Z * cap])
-                             : f3(sh[(size_t)SH_W1X * cap], sh[(size_t)SH_W1Y * cap], sh[(size_t)SH_W1Z * cap]);
+            const float4* sh = P.sh + (size_t)(it >> 1) * kShVec;
+            wr.p = xyz(sh[SHV_O]); wr.d = xyz(sh[(it & 1u) ? SHV_W2 : SHV_W1]);
         }
     };
     uint32_t qh = 0, nq = 0;                                     // leaf queue (ring): head, count -- wave-uniform
@@ -229,14 +238,17 @@ __global__ void __launch_bounds__(kExtBlock) k_trace(DScene S, DPaths P, Params 
                         const uint32_t idx = pool_next + (uint32_t)__popcll(need & lt);
                         if (idx < pool_end) {
                             slot = q ? q[idx] : idx;
-                            load_world(slot, wr);
                             rec = 0; state = LS_SETUP;
-                            if (!ANY) { best_t = kBig; best_inst = -1; best_mesh = -1; best_slot = 0; }
-                            else {
+                            if (!ANY) {
+                                wr.p = xyz(P.ray[2 * (size_t)slot]); wr.d = xyz(P.ray[2 * (size_t)slot + 1]);
+                                best_t = kBig; best_inst = -1; best_mesh = -1; best_slot = 0;
+                            } else {
                                 // (1) the light's own object, both sides: a miss or its back side blocks (raytracer.cpp:67-97,138-145)
-                                const float* sh = P.sh + (slot >> 1);
-                                const float tmax = (slot & 1u) ? kBig : sh[(size_t)SH_TMAX1 * cap];
-                                const DLight& L = S.lights[__float_as_int(sh[(size_t)SH_LIGHT * cap])];
+                                const float4* sh = P.sh + (size_t)(slot >> 1) * kShVec;
+                                const float4 so = sh[SHV_O], sw = sh[(slot & 1u) ? SHV_W2 : SHV_W1];
+                                wr.p = xyz(so); wr.d = xyz(sw);
+                                const float tmax = (slot & 1u) ? kBig : so.w;
+                                const DLight& L = S.lights[__float_as_int(sw.w)];
                                 linst = (uint32_t)L.inst;
                                 const float4* R = S.recs + (size_t)L.rec * kRecStride;
                                 const Ray lr = rec_ray(S, R, __float_as_uint(R[0].y), linst, wr);
@@ -257,7 +269,7 @@ __global__ void __launch_bounds__(kExtBlock) k_trace(DScene S, DPaths P, Params 
                     for (;;) {
                         if (rec >= (uint32_t)S.num_recs) {
                             if (ANY) P.vis[slot] = 0;
-                            else { P.ht[slot] = best_t; P.hinst[slot] = best_inst; P.hmesh[slot] = best_mesh; P.hslot[slot] = best_slot; }
+                            else store_hit(P, slot, best_t, best_inst, best_mesh, best_slot);
                             state = LS_IDLE;
                             break;
                         }
@@ -443,7 +455,7 @@ __global__ void __launch_bounds__(kExtBlock) k_trace(DScene S, DPaths P, Params 
             }
             if (state == LS_SETUP && rec >= (uint32_t)S.num_recs) {      // that was the last object: report now, the lane is idle
                 if (ANY) P.vis[slot] = 0;
-                else { P.ht[slot] = best_t; P.hinst[slot] = best_inst; P.hmesh[slot] = best_mesh; P.hslot[slot] = best_slot; }
+                else store_hit(P, slot, best_t, best_inst, best_mesh, best_slot);
                 state = LS_IDLE;
             }
         }
@@ -490,24 +502,23 @@ __global__ void __launch_bounds__(kBlock) k_shade(DScene S, DCamera cam, DPaths 
     const uint32_t* q = bounce == 0 ? nullptr : P.queue[bounce & 1];
     uint32_t* qnext = P.queue[(bounce + 1) & 1];
     const uint32_t nround = (n + 63u) & ~63u;
-    const size_t cap = P.cap;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < nround; i += gridDim.x * blockDim.x) {
         bool alive = false, shadow = false;
         uint32_t slot = 0, vflags = 0;
         if (i < n) {
             slot = q ? q[i] : i;
-            const uint32_t pixel = P.pix[slot], sample = P.smp[slot];
-            Rng rng; rng.init(prm.seed, pixel, sample, P.draw[slot]);
+            const uint4 id = P.id[slot];
+            const uint32_t pixel = id.x, sample = id.y;
+            Rng rng; rng.init(prm.seed, pixel, sample, id.z);
             Ray r; F3 rd = f3(0, 0, 0), td = f3(0, 0, 0);
             const bool hasDiff = bounce == 0;
             if (bounce == 0) camera_rays(cam, prm.seed, pixel, sample, prm.width, true, r, rd, td);
-            else { r.p = f3(P.ray[slot], P.ray[cap + slot], P.ray[2 * cap + slot]);
-                   r.d = f3(P.ray[3 * cap + slot], P.ray[4 * cap + slot], P.ray[5 * cap + slot]); }
-            HitRec hr; hr.t = P.ht[slot]; hr.inst = P.hinst[slot]; hr.mesh = P.hmesh[slot]; hr.slot = P.hslot[slot];
-            F3 T = PT_LD3(P.T, cap, slot), C = PT_LD3(P.C, cap, slot);
+            else { r.p = xyz(P.ray[2 * (size_t)slot]); r.d = xyz(P.ray[2 * (size_t)slot + 1]); }
+            const HitRec hr = load_hit(P, slot);
+            F3 T = xyz(P.T[slot]), C = xyz(P.C[slot]);
             if (hr.inst < 0) {                                     // render.h:124-128
                 C = C + T * sample_environment(S, r.d);
-                PT_ST3(P.C, cap, slot, C);
+                P.C[slot] = f4(C, 0.0f);
             } else {
                 Surf h;
                 surf_from_hit(S, hr, r, hasDiff, rd, td, h);
@@ -552,17 +563,9 @@ __global__ void __launch_bounds__(kBlock) k_shade(DScene S, DCamera cam, DPaths 
                         }
                         if (flags) {
                             const F3 so = h.p + h.N * kBias;
-                            float* sh = P.sh + slot;
-#define PT_SH(f) sh[(size_t)(f) * cap]
-                            PT_SH(SH_OX) = so.x; PT_SH(SH_OY) = so.y; PT_SH(SH_OZ) = so.z;
-                            PT_SH(SH_W1X) = wi1.x; PT_SH(SH_W1Y) = wi1.y; PT_SH(SH_W1Z) = wi1.z; PT_SH(SH_TMAX1) = dist;
-                            PT_SH(SH_C1X) = c1.x; PT_SH(SH_C1Y) = c1.y; PT_SH(SH_C1Z) = c1.z;
-                            PT_SH(SH_W2X) = wi2.x; PT_SH(SH_W2Y) = wi2.y; PT_SH(SH_W2Z) = wi2.z;
-                            PT_SH(SH_A2X) = A2.x; PT_SH(SH_A2Y) = A2.y; PT_SH(SH_A2Z) = A2.z; PT_SH(SH_PDFB) = pdf2;
-                            PT_SH(SH_HPX) = h.p.x; PT_SH(SH_HPY) = h.p.y; PT_SH(SH_HPZ) = h.p.z;
-                            PT_SH(SH_TBX) = T.x; PT_SH(SH_TBY) = T.y; PT_SH(SH_TBZ) = T.z; PT_SH(SH_SELPDF) = selectPdf;
-                            PT_SH(SH_FLAGS) = __uint_as_float(flags); PT_SH(SH_LIGHT) = __int_as_float(li);
-#undef PT_SH
+                            float4* sh = P.sh + (size_t)slot * kShVec;
+                            sh[SHV_O] = f4(so, dist); sh[SHV_W1] = f4(wi1, __int_as_float(li)); sh[SHV_W2] = f4(wi2, __int_as_float(li));
+                            sh[SHV_C1] = f4(c1, pdf2); sh[SHV_A2] = f4(A2, selectPdf); sh[SHV_HP] = f4(h.p, __uint_as_float(flags)); sh[SHV_TB] = f4(T, 0.0f);
                             shadow = true; vflags = flags;
                         }
                     }
@@ -583,12 +586,11 @@ __global__ void __launch_bounds__(kBlock) k_shade(DScene S, DCamera cam, DPaths 
                     else T = T * (1.0f / p);
                 }
                 if (bounce + 1 >= prm.max_bounces) alive = false;
-                PT_ST3(P.C, cap, slot, C);
+                P.C[slot] = f4(C, 0.0f);
                 if (alive) {
-                    PT_ST3(P.T, cap, slot, T);
-                    P.ray[slot] = np.x; P.ray[cap + slot] = np.y; P.ray[2 * cap + slot] = np.z;
-                    P.ray[3 * cap + slot] = wi.x; P.ray[4 * cap + slot] = wi.y; P.ray[5 * cap + slot] = wi.z;
-                    P.draw[slot] = rng.draw;
+                    P.T[slot] = f4(T, 0.0f);
+                    P.ray[2 * (size_t)slot] = f4(np, 0.0f); P.ray[2 * (size_t)slot + 1] = f4(wi, 0.0f);
+                    P.id[slot] = make_uint4(pixel, sample, rng.draw, 0u);
                 }
             }
         }
@@ -605,40 +607,38 @@ __global__ void __launch_bounds__(kBlock) k_shade(DScene S, DCamera cam, DPaths 
 // done by k_trace<ANY>; this kernel combines their results.
 __global__ void __launch_bounds__(kBlock) k_connect(DScene S, DPaths P, uint32_t bounce) {
     const uint32_t n = P.scounts[bounce];
-    const size_t cap = P.cap;
     unsigned long long rays = 0;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const uint32_t slot = P.squeue[i];
-        const float* sh = P.sh + slot;
-#define PT_SH(f) sh[(size_t)(f) * cap]
-        const uint32_t flags = __float_as_uint(PT_SH(SH_FLAGS));
+        const float4* sh = P.sh + (size_t)slot * kShVec;
+        const float4 w2 = sh[SHV_W2], c1 = sh[SHV_C1], a2 = sh[SHV_A2], hpf = sh[SHV_HP];
+        const uint32_t flags = __float_as_uint(hpf.w);
         F3 direct = f3(0, 0, 0);
         if (flags & 1u) {
             rays++;
-            if (!P.vis[2 * (size_t)slot]) direct = direct + f3(PT_SH(SH_C1X), PT_SH(SH_C1Y), PT_SH(SH_C1Z));
+            if (!P.vis[2 * (size_t)slot]) direct = direct + xyz(c1);
         }
         if (flags & 2u) {
             rays++;
             if (!P.vis[2 * (size_t)slot + 1]) {
                 // the light's hit point / normal of LightVisTest's first sweep (raytracer.cpp:67-97), for LightComponent::Pdf(wi)
-                const DLight& L = S.lights[__float_as_int(PT_SH(SH_LIGHT))];
-                Ray r; r.p = f3(PT_SH(SH_OX), PT_SH(SH_OY), PT_SH(SH_OZ)); r.d = f3(PT_SH(SH_W2X), PT_SH(SH_W2Y), PT_SH(SH_W2Z));
+                const DLight& L = S.lights[__float_as_int(sh[SHV_W1].w)];
+                Ray r; r.p = xyz(sh[SHV_O]); r.d = xyz(w2);
                 F3 lp, ln;
                 light_hit_point(S, r, L, lp, ln);
-                const F3 hp = f3(PT_SH(SH_HPX), PT_SH(SH_HPY), PT_SH(SH_HPZ));
+                const F3 hp = xyz(hpf);
                 const float lightPdf = light_pdf(L, hp, lp, ln, len(lp - hp));
                 if (!(lightPdf <= 0.0f)) {
-                    const float pb = PT_SH(SH_PDFB);
+                    const float pb = c1.w;
                     const float w = (pb * pb) / (pb * pb + lightPdf * lightPdf);
-                    direct = direct + f3(PT_SH(SH_A2X), PT_SH(SH_A2Y), PT_SH(SH_A2Z)) * w / pb;
+                    direct = direct + xyz(a2) * w / pb;
                 }
             }
         }
-        const F3 Tb = f3(PT_SH(SH_TBX), PT_SH(SH_TBY), PT_SH(SH_TBZ));
-        F3 C = PT_LD3(P.C, cap, slot);
-        C = C + Tb * (direct / PT_SH(SH_SELPDF));
-        PT_ST3(P.C, cap, slot, C);
-#undef PT_SH
+        const F3 Tb = xyz(sh[SHV_TB]);
+        F3 C = xyz(P.C[slot]);
+        C = C + Tb * (direct / a2.w);
+        P.C[slot] = f4(C, 0.0f);
     }
     wave_add64(rays, &P.stat[1]);
 }
@@ -661,7 +661,7 @@ __global__ void __launch_bounds__(kBlock) k_resolve(DPaths P, float* mean, uint3
         uint32_t n = cnt[pixel];
         for (uint32_t s = 0; s < ns; s++) {
             const uint32_t slot = s * npix_chunk + i;
-            const F3 smp = finish_sample(PT_LD3(P.C, P.cap, slot), nullptr);
+            const F3 smp = finish_sample(xyz(P.C[slot]), nullptr);
             n += 1;
             const float factor = 1.0f / (float)n;
             c = ((float)(n - 1) * c + smp) * factor;
@@ -675,7 +675,7 @@ __global__ void __launch_bounds__(kBlock) k_resolve(DPaths P, float* mean, uint3
 __global__ void __launch_bounds__(kBlock) k_gather(DPaths P, uint32_t n, float* linear, float* mapped) {
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         F3 lin;
-        const F3 m = finish_sample(PT_LD3(P.C, P.cap, i), &lin);
+        const F3 m = finish_sample(xyz(P.C[i]), &lin);
         if (linear) { linear[3 * (size_t)i] = lin.x; linear[3 * (size_t)i + 1] = lin.y; linear[3 * (size_t)i + 2] = lin.z; }
         if (mapped) { mapped[3 * (size_t)i] = m.x; mapped[3 * (size_t)i + 1] = m.y; mapped[3 * (size_t)i + 2] = m.z; }
     }
@@ -694,12 +694,12 @@ __global__ void __launch_bounds__(kBlock) k_primary_init(DPaths P, Params prm, u
     const uint32_t n = rw * rh;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const uint32_t ly = i / rw, lx = i - ly * rw;
-        P.pix[i] = (y0 + ly) * prm.width + (x0 + lx); P.smp[i] = 0;
+        P.id[i] = make_uint4((y0 + ly) * prm.width + (x0 + lx), 0u, 2u, 0u);
     }
 }
 __global__ void __launch_bounds__(kBlock) k_primary_out(DScene S, DPaths P, uint32_t n, int32_t* node, int32_t* mesh, int32_t* face, float* t) {
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        HitRec h; h.t = P.ht[i]; h.inst = P.hinst[i]; h.mesh = P.hmesh[i]; h.slot = P.hslot[i];
+        const HitRec h = load_hit(P, i);
         t[i] = h.t;
         if (h.inst < 0) { node[i] = -1; mesh[i] = -1; face[i] = -1; }
         else {
@@ -1069,10 +1069,8 @@ int mi355pt_render_create(mi355pt_scene* scene, const mi355pt_render_params* par
     cap = (cap + 63) & ~(size_t)63;
     auto dalloc = [&](void** p, size_t bytes) -> hipError_t { hipError_t e = hipMalloc(p, bytes); if (e == hipSuccess) r->allocs.push_back(*p); return e; };
     DPaths& P = r->P; P.cap = (uint32_t)cap;
-    HIP_TRY(dalloc((void**)&P.pix, cap * 4)); HIP_TRY(dalloc((void**)&P.smp, cap * 4)); HIP_TRY(dalloc((void**)&P.draw, cap * 4));
-    HIP_TRY(dalloc((void**)&P.ray, cap * 24)); HIP_TRY(dalloc((void**)&P.T, cap * 12)); HIP_TRY(dalloc((void**)&P.C, cap * 12));
-    HIP_TRY(dalloc((void**)&P.ht, cap * 4)); HIP_TRY(dalloc((void**)&P.hinst, cap * 4)); HIP_TRY(dalloc((void**)&P.hmesh, cap * 4)); HIP_TRY(dalloc((void**)&P.hslot, cap * 4));
-    HIP_TRY(dalloc((void**)&P.sh, cap * 4 * kShFields));
+    HIP_TRY(dalloc((void**)&P.id, cap * 16)); HIP_TRY(dalloc((void**)&P.ray, cap * 32)); HIP_TRY(dalloc((void**)&P.T, cap * 16)); HIP_TRY(dalloc((void**)&P.C, cap * 16));
+    HIP_TRY(dalloc((void**)&P.hit, cap * 16)); HIP_TRY(dalloc((void**)&P.sh, cap * 16 * kShVec));
     HIP_TRY(dalloc((void**)&P.queue[0], cap * 4)); HIP_TRY(dalloc((void**)&P.queue[1], cap * 4)); HIP_TRY(dalloc((void**)&P.squeue, cap * 4));
     const size_t nb = params->max_bounces + 2;
     HIP_TRY(dalloc((void**)&P.counts, nb * 4)); HIP_TRY(dalloc((void**)&P.scounts, nb * 4)); HIP_TRY(dalloc((void**)&P.work, nb * 4));
@@ -1275,13 +1273,15 @@ int mi355pt_trace_rays(mi355pt_render* r, const float* origins, const float* dir
     if (count == 0) return MI355PT_OK;
     if (count > r->P.cap) return fail(MI355PT_ERR_TOO_LARGE, "more rays than path slots");
     HIP_TRY(hipSetDevice(r->scene->device));
-    const size_t n = count, cap = r->P.cap;
+    const size_t n = count;
     int32_t *dn, *dm, *df; float* dt;
     HIP_TRY(hipMalloc((void**)&dn, n * 4)); HIP_TRY(hipMalloc((void**)&dm, n * 4)); HIP_TRY(hipMalloc((void**)&df, n * 4)); HIP_TRY(hipMalloc((void**)&dt, n * 4));
-    std::vector<float> soa(6 * n);
-    for (size_t i = 0; i < n; i++) for (int c = 0; c < 3; c++) { soa[c * n + i] = origins[3 * i + c]; soa[(3 + c) * n + i] = dirs[3 * i + c]; }
-    hipError_t e = hipSuccess;
-    for (int c = 0; c < 6 && e == hipSuccess; c++) e = hipMemcpy(r->P.ray + c * cap, soa.data() + c * n, n * 4, hipMemcpyHostToDevice);
+    std::vector<float4> rays(2 * n);
+    for (size_t i = 0; i < n; i++) {
+        rays[2 * i] = make_float4(origins[3 * i], origins[3 * i + 1], origins[3 * i + 2], 0.0f);
+        rays[2 * i + 1] = make_float4(dirs[3 * i], dirs[3 * i + 1], dirs[3 * i + 2], 0.0f);
+    }
+    hipError_t e = hipMemcpy(r->P.ray, rays.data(), rays.size() * sizeof(float4), hipMemcpyHostToDevice);
     if (e == hipSuccess) {
         const int rc = run_paths(r, (uint32_t)n, 2, 1);
         (void)rc;
