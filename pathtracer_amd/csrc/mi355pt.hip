@@ -149,15 +149,17 @@ __global__ void __launch_bounds__(kBlock) k_raygen(DCamera cam, DPaths P, Params
 enum { LS_IDLE = 0, LS_SETUP, LS_TRAV, LS_WAIT, LS_THIEF, LS_DONE };
 constexpr int kExtBlock = 64;
 constexpr uint32_t kLeafQ = 256;         // leaf items per wave; a node step needs room for 2 x 64
-constexpr uint32_t kNodeLanes = 40;      // the node loop yields when fewer lanes than this can take a step (MI355PT_NODE_LANES)
+constexpr uint32_t kNodeLanes = 24;      // the node loop yields when fewer lanes than this can take a step (MI355PT_NODE_LANES)
 constexpr uint32_t kMaxLeaf = ptb::kMaxLeaf;
 constexpr uint32_t kExtendGuard = 1u << 22;
 static_assert(kMaxLeaf == 4, "leaf items carry count-1 in 2 bits and the triangle list holds 64 x 4 entries");
 
 // LDS of one wave, in dwords, after the stack of `E` entries x 64 lanes
-constexpr uint32_t kLdsQRef = 0, kLdsQOwn = kLdsQRef + kLeafQ, kLdsRay = kLdsQOwn + kLeafQ, kLdsKey = kLdsRay + 64 * 8,
-                   kLdsWork = kLdsKey + 64 * 2, kLdsXfer = kLdsWork + 64, kLdsTri = kLdsXfer + 128, kLdsEnd = kLdsTri + 64;
-static_assert((kLdsRay % 4) == 0 && (kLdsKey % 2) == 0, "alignment of the float4 / u64 parts");
+constexpr uint32_t kRecCache = 3;        // walk records kept in LDS (a scene of a few objects is walked without touching memory)
+constexpr uint32_t kLdsQRef = 0, kLdsQOwn = kLdsQRef + kLeafQ, kLdsRay = kLdsQOwn + kLeafQ / 4, kLdsKey = kLdsRay + 64 * 8,
+                   kLdsWork = kLdsKey + 64 * 2, kLdsXfer = kLdsWork + 64, kLdsTri = kLdsXfer + 128, kLdsRec = kLdsTri + 64,
+                   kLdsEnd = kLdsRec + kRecCache * kRecStride * 4;
+static_assert((kLdsRay % 4) == 0 && (kLdsKey % 2) == 0 && (kLdsRec % 4) == 0, "alignment of the float4 / u64 parts");
 inline size_t extend_lds_bytes(uint32_t entries) { return ((size_t)entries * 64 + kLdsEnd) * 4; }
 
 // (t, slot) as one ordered 64-bit key.  Accepted distances are >= 0 or -0.0 (the reference rejects only t < 0 and
@@ -184,7 +186,7 @@ __global__ void __launch_bounds__(kExtBlock) k_trace(DScene S, DPaths P, Params 
     const unsigned long long lt = (1ull << lane) - 1ull;
     uint32_t* stk = sm;                                          // [E][64]
     uint32_t* aux = sm + prm.stack_entries * 64;
-    uint32_t* qref = aux + kLdsQRef; uint32_t* qown = aux + kLdsQOwn;
+    uint32_t* qref = aux + kLdsQRef; uint8_t* qown = (uint8_t*)(aux + kLdsQOwn);
     float4* rayl = (float4*)(aux + kLdsRay);                     // [64][2]: (o, -), (d, -) of the owner's ray in mesh space
     unsigned long long* keyl = (unsigned long long*)(aux + kLdsKey);   // [64] best (t, slot) of the owner's current mesh
     uint32_t* nwork = aux + kLdsWork;                            // [64] lanes still walking for this owner
@@ -207,7 +209,18 @@ __global__ void __launch_bounds__(kExtBlock) k_trace(DScene S, DPaths P, Params 
     };
     uint32_t qh = 0, nq = 0;                                     // leaf queue (ring): head, count -- wave-uniform
     const uint32_t nwaves = gridDim.x;
+    // Queue chunk per atomic: up to 1024 rays while there is plenty of work per wave.  A short queue (the late bounces:
+    // a few thousand surviving paths) is dealt out a few rays per wave and pass instead, so that every CU gets some
+    // and the lanes without a ray of their own walk stolen subtrees of those few -- the launch is then bounded by
+    // latency, not by the one wave that happened to take 64 long rays.
     uint32_t chunk = (n / (8u * nwaves)) & ~63u; chunk = chunk < 64u ? 64u : (chunk > 1024u ? 1024u : chunk);
+    const bool trickle = n < 64u * nwaves;
+    if (trickle) { chunk = (n + nwaves - 1u) / nwaves; chunk = chunk < 4u ? 4u : chunk; }
+    if (blockIdx.x * chunk >= n) return;                         // nothing left for this wave even on the first deal
+    float4* recl = (float4*)(aux + kLdsRec);
+    const uint32_t ncache = (uint32_t)S.num_recs < kRecCache ? (uint32_t)S.num_recs : kRecCache;
+    for (uint32_t i = lane; i < ncache * kRecStride; i += 64u) recl[i] = S.recs[i];
+    __syncthreads();
     uint32_t pool_next = 0, pool_end = 0; bool exhausted = false;
     uint32_t guard = 0;
     // counting builds: wave cycles per phase, passes, node-loop lanes (stats.debug, tools/diag_bounces.py)
@@ -223,11 +236,13 @@ __global__ void __launch_bounds__(kExtBlock) k_trace(DScene S, DPaths P, Params 
         {
             Ray wr; wr.p = wr.d = f3(0, 0, 0);
             if (state == LS_SETUP) load_world(slot, wr);
+            bool claimed = false;
             for (;;) {
                 if (state == LS_IDLE && lane >= prm.owner_lanes) state = LS_DONE;     // test knob: these lanes only ever steal
                 const unsigned long long need = __ballot(state == LS_IDLE);
                 if (need) {
-                    if (pool_next >= pool_end && !exhausted) {       // one atomic on the global counter per chunk
+                    if (pool_next >= pool_end && !exhausted && !(trickle && claimed)) {       // one atomic on the global counter per chunk
+                        claimed = true;
                         uint32_t base = 0;
                         if (lane == 0) base = atomicAdd(work, chunk);
                         base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
@@ -250,7 +265,7 @@ __global__ void __launch_bounds__(kExtBlock) k_trace(DScene S, DPaths P, Params 
                                 const float tmax = (slot & 1u) ? kBig : so.w;
                                 const DLight& L = S.lights[__float_as_int(sw.w)];
                                 linst = (uint32_t)L.inst;
-                                const float4* R = S.recs + (size_t)L.rec * kRecStride;
+                                const float4* R = (uint32_t)L.rec < ncache ? (const float4*)(recl + L.rec * kRecStride) : S.recs + (size_t)L.rec * kRecStride;
                                 const Ray lr = rec_ray(S, R, __float_as_uint(R[0].y), linst, wr);
                                 float lz; bool front; F3 Pp;
                                 if (!plane_hit(lr.p, lr.d, SIDE_BOTH, lz, front, Pp) || !front) { P.vis[slot] = 1; state = LS_IDLE; }
@@ -261,7 +276,8 @@ __global__ void __launch_bounds__(kExtBlock) k_trace(DScene S, DPaths P, Params 
                     const uint32_t took = (uint32_t)__popcll(need);
                     pool_next = pool_end - pool_next < took ? pool_end : pool_next + took;
                 }
-                if (__ballot(state == LS_SETUP || state == LS_IDLE) == 0) break;
+                const bool more = pool_next < pool_end || (!exhausted && !(trickle && claimed));      // could an idle lane still get a ray in this pass?
+                if (__ballot(state == LS_SETUP || (state == LS_IDLE && more)) == 0) break;
                 // ---- TraceNode's / LightVisTest's walk over the objects (earlier object wins ties, raytracer.cpp:208,238),
                 // record by record, until a mesh has to be traversed or the ray is finished
                 uint32_t root_leaf = 0;                               // leaf item to enqueue when a mesh's root is a leaf
@@ -273,7 +289,7 @@ __global__ void __launch_bounds__(kExtBlock) k_trace(DScene S, DPaths P, Params 
                             state = LS_IDLE;
                             break;
                         }
-                        const float4* R = S.recs + (size_t)rec * kRecStride;
+                        const float4* R = rec < ncache ? (const float4*)(recl + rec * kRecStride) : S.recs + (size_t)rec * kRecStride;
                         const float4 h0 = R[0], h1 = R[1];
                         const uint32_t kind = __float_as_uint(h0.x), clen = __float_as_uint(h0.y), nexti = __float_as_uint(h0.z), rflags = __float_as_uint(h0.w);
                         const uint32_t rii = __float_as_uint(h1.x);
@@ -316,7 +332,7 @@ __global__ void __launch_bounds__(kExtBlock) k_trace(DScene S, DPaths P, Params 
                 }
                 const unsigned long long rl = __ballot(root_leaf != 0u);
                 if (rl) {                                             // at most one per lane per setup phase, the queue was empty
-                    if (root_leaf) { const uint32_t pos = (qh + nq + (uint32_t)__popcll(rl & lt)) % kLeafQ; qref[pos] = root_leaf; qown[pos] = lane; }
+                    if (root_leaf) { const uint32_t pos = (qh + nq + (uint32_t)__popcll(rl & lt)) % kLeafQ; qref[pos] = root_leaf; qown[pos] = (uint8_t)lane; }
                     nq += (uint32_t)__popcll(rl);
                 }
             }
@@ -328,12 +344,16 @@ __global__ void __launch_bounds__(kExtBlock) k_trace(DScene S, DPaths P, Params 
         {
             const uint32_t ntrav = (uint32_t)__popcll(__ballot(state == LS_TRAV || state == LS_THIEF));
             uint32_t th = (3u * ntrav + 3u) / 4u; th = th > prm.node_lanes ? prm.node_lanes : th;
+            // with many lanes free to steal, come back to the steal phase after a couple of steps: work doubles per pass
+            const uint32_t nfree = (uint32_t)__popcll(__ballot(state == LS_DONE || (trickle && state == LS_IDLE)));
+            const uint32_t max_it = nfree >= 16u ? 2u : 0xFFFFFFFFu;
+            uint32_t it = 0;
             bool first = true;
             for (;;) {
                 const bool want = (state == LS_TRAV || state == LS_THIEF) && sp > sb;
                 const uint32_t nw = (uint32_t)__popcll(__ballot(want));
-                if (nw == 0 || (!first && nw < th) || kLeafQ - nq < 128u) break;
-                first = false;
+                if (nw == 0 || (!first && nw < th) || kLeafQ - nq < 128u || it >= max_it) break;
+                first = false; it++;
                 if (COUNT) { n_node_it++; n_node_act += nw; }
                 uint32_t leafL = 0, leafR = 0;
                 if (want) {
@@ -388,13 +408,13 @@ __global__ void __launch_bounds__(kExtBlock) k_trace(DScene S, DPaths P, Params 
                 const unsigned long long mL = __ballot(leafL != 0u), mR = __ballot(leafR != 0u);
                 if (mL | mR) {
                     const uint32_t cL = (uint32_t)__popcll(mL);
-                    if (leafL) { const uint32_t pos = (qh + nq + (uint32_t)__popcll(mL & lt)) % kLeafQ; qref[pos] = leafL; qown[pos] = owner; }
-                    if (leafR) { const uint32_t pos = (qh + nq + cL + (uint32_t)__popcll(mR & lt)) % kLeafQ; qref[pos] = leafR; qown[pos] = owner; }
+                    if (leafL) { const uint32_t pos = (qh + nq + (uint32_t)__popcll(mL & lt)) % kLeafQ; qref[pos] = leafL; qown[pos] = (uint8_t)owner; }
+                    if (leafR) { const uint32_t pos = (qh + nq + cL + (uint32_t)__popcll(mR & lt)) % kLeafQ; qref[pos] = leafR; qown[pos] = (uint8_t)owner; }
                     nq += cL + (uint32_t)__popcll(mR);
                 }
                 if (want && sp == sb) {                               // this lane's share of the ray is walked
                     atomicSub(&nwork[owner], 1u);
-                    state = state == LS_TRAV ? LS_WAIT : LS_DONE;
+                    state = state == LS_TRAV ? LS_WAIT : (exhausted ? LS_DONE : LS_IDLE);
                 }
             }
         }
@@ -438,7 +458,7 @@ __global__ void __launch_bounds__(kExtBlock) k_trace(DScene S, DPaths P, Params 
         if (state == LS_TRAV || state == LS_THIEF) {
             const unsigned long long k = keyl[owner];
             if (!ANY) bt = __uint_as_float((uint32_t)(k >> 32));
-            else if (k) { sp = sb; atomicSub(&nwork[owner], 1u); state = state == LS_TRAV ? LS_WAIT : LS_DONE; }   // blocked: abandon the walk
+            else if (k) { sp = sb; atomicSub(&nwork[owner], 1u); state = state == LS_TRAV ? LS_WAIT : (exhausted ? LS_DONE : LS_IDLE); }   // blocked: abandon the walk
         }
         __syncthreads();
         if (state == LS_WAIT && nwork[lane] == 0u) {                    // every lane that walked for this ray is done, the queue is empty
@@ -459,8 +479,10 @@ __global__ void __launch_bounds__(kExtBlock) k_trace(DScene S, DPaths P, Params 
                 state = LS_IDLE;
             }
         }
-        if (exhausted || prm.owner_lanes < 64u) {
-            const unsigned long long idle = __ballot(state == LS_DONE);
+        {   // lanes without a ray (queue empty, or a short queue dealt out thinly) take over subtrees of busy lanes;
+            // with a long queue an idle lane simply gets its next ray in the coming set-up
+            const bool free_lane = state == LS_DONE || (trickle && state == LS_IDLE);
+            const unsigned long long idle = __ballot(free_lane);
             const bool can_give = (state == LS_TRAV || state == LS_THIEF) && sp - sb >= 2u;
             const unsigned long long donors = __ballot(can_give);
             const uint32_t ni = (uint32_t)__popcll(idle), nd = (uint32_t)__popcll(donors);
@@ -471,7 +493,7 @@ __global__ void __launch_bounds__(kExtBlock) k_trace(DScene S, DPaths P, Params 
                     if (r < k) { xfer[r] = PT_STK(sb); xfer[64 + r] = owner; sb++; atomicAdd(&nwork[owner], 1u); }
                 }
                 __syncthreads();
-                if (state == LS_DONE) {
+                if (free_lane) {
                     const uint32_t r = (uint32_t)__popcll(idle & lt);
                     if (r < k) {
                         owner = xfer[64 + r];
@@ -497,7 +519,10 @@ __global__ void __launch_bounds__(kExtBlock) k_trace(DScene S, DPaths P, Params 
 // ---------------------------------------------------------------------- shade
 // RenderPixel's loop body for one bounce (render.h:121-206) minus the two visibility traces,
 // which are queued for k_connect.
-__global__ void __launch_bounds__(kBlock) k_shade(DScene S, DCamera cam, DPaths P, Params prm, uint32_t bounce, uint32_t n0) {
+#ifndef PT_SHADE_WAVES
+#define PT_SHADE_WAVES 1
+#endif
+__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PT_SHADE_WAVES, 8))) k_shade(DScene S, DCamera cam, DPaths P, Params prm, uint32_t bounce, uint32_t n0) {
     const uint32_t n = bounce == 0 ? n0 : P.counts[bounce];
     const uint32_t* q = bounce == 0 ? nullptr : P.queue[bounce & 1];
     uint32_t* qnext = P.queue[(bounce + 1) & 1];
@@ -1087,7 +1112,7 @@ int mi355pt_render_create(mi355pt_scene* scene, const mi355pt_render_params* par
     r->grid = prop.multiProcessorCount * 8;
     {   // persistent extend kernel: one wave per workgroup, LDS = stack of (tree depth + 4) dwords per lane + the wave's
         // queues; the grid is the number of waves that are resident at once
-        const int entries = std::min(kStackSize, std::max(8, scene->max_depth + 4));
+        const int entries = std::min(kStackSize, std::max(8, scene->max_depth + 3));
         r->stack_entries = (uint32_t)entries;
         r->extend_lds = extend_lds_bytes((uint32_t)entries);
         int waves = 0;

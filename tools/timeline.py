@@ -1,0 +1,10 @@
+"""Per-launch timeline (us) of the last render step in a rocprofv3 kernel-trace database."""
+import sqlite3, sys
+c = sqlite3.connect(sys.argv[1])
+rows = c.execute("select name, start, end from kernels order by start").fetchall()
+last = max(i for i, r in enumerate(rows) if r[0].startswith("k_raygen"))
+out = []
+for n, s, e in rows[last:]:
+    short = 'ext' if 'k_trace<false' in n else 'vis' if 'k_trace<true' in n else n.split('(')[0][:9]
+    out.append(f"{short}:{(e - s) / 1000:.0f}")
+print(' '.join(out))
