@@ -431,22 +431,32 @@ __global__ void __launch_bounds__(kExtBlock) k_trace(DScene S, DPaths P, Params 
             const uint32_t total = (uint32_t)__popcll(b0) + 2u * (uint32_t)__popcll(b1) + m;
             if (has) for (uint32_t k = 0; k <= c1; k++) tril[pre + k] = (uint8_t)((lane << 2) | k);
             __syncthreads();
-            for (uint32_t base = 0; base < total; base += 64u) {
-                const uint32_t idx = base + lane;
-                if (COUNT) { n_drain_it++; n_drain_act += total - base < 64u ? total - base : 64u; }
-                if (idx < total) {
-                    const uint32_t code = tril[idx];
-                    const uint32_t pos = (qh + (code >> 2)) % kLeafQ;
-                    const uint32_t tslot = (qref[pos] & kLeafSlotMask) + (code & 3u);
-                    const uint32_t own = qown[pos];
-                    const float4 ro = rayl[2 * own], rd = rayl[2 * own + 1];
-                    const unsigned long long cur = keyl[own];
-                    const Tri T = load_tri(S.tris, tslot);
+            // two triangles per lane and pass: both fetches are in flight before either test runs
+            for (uint32_t base = 0; base < total; base += 128u) {
+                if (COUNT) { const uint32_t left = total - base; n_drain_it += left > 64u ? 2u : 1u; n_drain_act += left < 128u ? left : 128u; }
+                uint32_t tslot[2] = {0u, 0u}, own[2] = {0u, 0u};
+                bool act[2];
+                for (int u = 0; u < 2; u++) {
+                    const uint32_t idx = base + 64u * (uint32_t)u + lane;
+                    act[u] = idx < total;
+                    if (act[u]) {
+                        const uint32_t code = tril[idx];
+                        const uint32_t pos = (qh + (code >> 2)) % kLeafQ;
+                        tslot[u] = (qref[pos] & kLeafSlotMask) + (code & 3u);
+                        own[u] = qown[pos];
+                    }
+                }
+                const Tri T0 = load_tri(S.tris, tslot[0]), T1 = load_tri(S.tris, tslot[1]);     // slot 0 for an idle half: harmless
+                for (int u = 0; u < 2; u++) {
+                    if (!act[u]) continue;
+                    const Tri& T = u ? T1 : T0;
+                    const float4 ro = rayl[2 * own[u]], rd = rayl[2 * own[u] + 1];
+                    const unsigned long long cur = keyl[own[u]];
                     if (COUNT) wc.tris++;
-                    if (ANY) { if (cur == 0ull && tri_any_front(T, f3(ro.x, ro.y, ro.z), f3(rd.x, rd.y, rd.z), ro.w)) keyl[own] = 1ull; }
+                    if (ANY) { if (cur == 0ull && tri_any_front(T, f3(ro.x, ro.y, ro.z), f3(rd.x, rd.y, rd.z), ro.w)) keyl[own[u]] = 1ull; }
                     else {
                         unsigned long long ck;
-                        if (tri_closest_key(T, f3(ro.x, ro.y, ro.z), f3(rd.x, rd.y, rd.z), tslot, cur, ck)) atomicMin(&keyl[own], ck);
+                        if (tri_closest_key(T, f3(ro.x, ro.y, ro.z), f3(rd.x, rd.y, rd.z), tslot[u], cur, ck)) atomicMin(&keyl[own[u]], ck);
                     }
                 }
             }

@@ -28,6 +28,27 @@ enum { SIDE_FRONT = 1, SIDE_BACK = 2, SIDE_BOTH = 3 };
 // 1-2 ulp.  Evaluating in fp64 and rounding once gives the correctly rounded fp32 result (up to
 // double-rounding cases ~1e-8), so device samples follow the same branches as the CPU reference.
 // These sit in shading code, far off the traversal critical path.
+// sin and cos of one angle together.  Every call site's angle lies in [0, 2 pi] (2 pi * U, or an acos): one Cody-Waite
+// step (k * pi/2 in two parts) and the fdlibm kernel polynomials (|error| < 2^-57) in fp64, rounded once to fp32 --
+// a third of the instructions of two libm calls, which matters because shading is instruction-bound.
+PT_DEV void a_sincosf(float xf, float& s, float& c) {
+    const double x = (double)xf;
+    if (!(xf >= -0.5f && xf <= 7.0f)) { s = (float)sin(x); c = (float)cos(x); return; }
+    const double k = rint(x * 6.36619772367581382433e-01);
+    double r = fma(-k, 1.57079632679489655800e+00, x);
+    r = fma(-k, 6.12323399573676603587e-17, r);
+    const double z = r * r;
+    const double ps = fma(z, fma(z, fma(z, fma(z, fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08), 2.75573137070700676789e-06),
+                                        -1.98412698298579493134e-04), 8.33333333332248946124e-03), -1.66666666666666324348e-01);
+    const double sn = fma(r * z, ps, r);
+    const double pc = fma(z, fma(z, fma(z, fma(z, fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09), -2.75573143513906633035e-07),
+                                        2.48015872894767294178e-05), -1.38888888888741095749e-03), 4.16666666666666019037e-02);
+    const double cs = fma(z * z, pc, fma(z, -0.5, 1.0));
+    const int q = (int)k & 3;
+    const double ss = (q & 1) ? cs : sn, cc = (q & 1) ? sn : cs;
+    s = (float)((q & 2) ? -ss : ss);
+    c = (float)((q == 1 || q == 2) ? -cc : cc);
+}
 PT_DEV float a_sinf(float x) { return (float)sin((double)x); }
 PT_DEV float a_cosf(float x) { return (float)cos((double)x); }
 PT_DEV float a_powf(float x, float y) { return (float)pow((double)x, (double)y); }
@@ -121,7 +142,9 @@ PT_DEV void camera_rays(const DCamera& c, uint32_t seed, uint32_t pixel, uint32_
     const float S = rng.U();
     const float r = sqrtf(S) * c.dof;
     const float theta = rng.U() * kTwoPI;
-    const float lx = r * a_cosf(theta), ly = r * a_sinf(theta);
+    float sin_t, cos_t;
+    a_sincosf(theta, sin_t, cos_t);
+    const float lx = r * cos_t, ly = r * sin_t;
     const F3 right = ld3(c.right), up = ld3(c.up), front = ld3(c.front);
     const F3 lens = right * lx + up * ly;
     mainRay.p = ld3(c.pos) + right * lx + up * ly;

@@ -188,11 +188,13 @@ PT_DEV float dmax(float a, float b) { return a < b ? b : a; }
 PT_DEV float dclamp(float t, float l, float r) { t = dmin(r, t); t = dmax(l, t); return t; }
 PT_DEV float mixf(float a, float b, float r) { return a * (1.0f - r) + b * r; }
 PT_DEV F3 mixv(F3 a, F3 b, float r) { return a * (1.0f - r) + b * r; }
-PT_DEV float gtr1(float NdotH, float a) {
+// GTR1 with log(a * a) supplied: `a` depends on the material only, so its logarithm is taken once per vertex
+// (disney_finish) instead of in each of the six pdf / eval calls of the vertex.
+PT_DEV float gtr1(float NdotH, float a, float log_a2) {
     if (a >= 1.0f) return kInvPI;
     const float a2 = a * a;
     const float t = 1.0f + (a2 - 1.0f) * NdotH * NdotH;
-    return (a2 - 1.0f) / (kPI * a_logf(a2) * t);
+    return (a2 - 1.0f) / (kPI * log_a2 * t);
 }
 PT_DEV float gtr2(float NdotH, float a) {
     const float a2 = a * a;
@@ -211,6 +213,7 @@ PT_DEV float schlick(float u) {
 struct Disney {
     F3 base;
     float metallic, specular, roughness, specularTint, sheenTint, sheen, clearcoatGloss, clearcoat, subsurface, csw;
+    float a_eval, log_eval, a_pdf, log_pdf;      // clearcoat GTR1 widths of DisneyEval / DisneyPdf and log(a * a) of each
 };
 PT_DEV void disney_finish(Disney& s) {      // Clamp + InitCSW (disneyBrdf.h:108-131)
     s.metallic = dclamp(s.metallic, 0.001f, 0.999f); s.specular = dclamp(s.specular, 0.001f, 0.999f);
@@ -224,11 +227,13 @@ PT_DEV void disney_finish(Disney& s) {      // Clamp + InitCSW (disneyBrdf.h:108
     const F3 c_spec0 = mixv((1.0f - s.specular * 0.3f) * mixv(f3(1, 1, 1), c_tint, s.specularTint), cd, s.metallic);
     const float cs_lum = dot(c_spec0, f3(0.3f, 0.6f, 0.1f));
     s.csw = cs_lum / (cs_lum + (1.0f - s.metallic) * cd_lum);
+    s.a_eval = mixf(0.1f, 0.001f, s.clearcoatGloss); s.log_eval = a_logf(s.a_eval * s.a_eval);
+    s.a_pdf = mixf(0.1f, 0.001f, s.a_eval); s.log_pdf = a_logf(s.a_pdf * s.a_pdf);
 }
 PT_DEV float disney_pdf(const Disney& s, float NdotH, float NdotL, float HdotL) {
     const float d_pdf = NdotL * (1.0f / kPI);
     const float r_pdf = gtr2(NdotH, dmax(0.001f, dmax(0.001f, s.roughness))) * NdotH / (4.0f * HdotL);
-    const float c_pdf = gtr1(NdotH, mixf(0.1f, 0.001f, mixf(0.1f, 0.001f, s.clearcoatGloss))) * NdotH / (4.0f * HdotL);
+    const float c_pdf = gtr1(NdotH, s.a_pdf, s.log_pdf) * NdotH / (4.0f * HdotL);
     return c_pdf * s.clearcoat + (1.0f - s.clearcoat) * (s.csw * r_pdf + (1.0f - s.csw) * d_pdf);
 }
 PT_DEV F3 disney_eval(const Disney& s, float NdotL, float NdotV, float NdotH, float HdotL) {
@@ -253,7 +258,7 @@ PT_DEV F3 disney_eval(const Disney& s, float NdotL, float NdotV, float NdotH, fl
     float gs = smith_ggx(NdotV, ro2);
     gs *= smith_ggx(NdotL, ro2);
     const F3 f_sheen = fh * s.sheen * c_sheen;
-    const float dr = gtr1(NdotH, mixf(0.1f, 0.001f, s.clearcoatGloss));
+    const float dr = gtr1(NdotH, s.a_eval, s.log_eval);
     const float fr = mixf(0.04f, 1.0f, fh);
     const float gr = smith_ggx(NdotV, 0.25f) * smith_ggx(NdotL, 0.25f);
     const F3 f = ((1.0f / kPI) * mixf(fd, ss, s.subsurface) * cd + f_sheen) * (1.0f - s.metallic) + gs * fs * ds + (0.25f * s.clearcoat) * gr * fr * dr;
@@ -265,35 +270,45 @@ PT_DEV F3 disney_sample(const Disney& s, F3 V, F3 N, Rng& rng) {
     const F3 U = fabsf(N.z) < (1.0f - kFltEps) ? f3(0.0f, 0.0f, 1.0f) : f3(1.0f, 0.0f, 0.0f);
     const F3 T = normalized(cross(U, N));
     const F3 B = cross(N, T);
+    // Lobe choice first (disneyBrdf.h:222-268), then ONE sin/cos for whichever lobe each lane took: the three
+    // lobes use the same expression for the azimuth, and a wave whose lanes disagree would otherwise run the
+    // transcendental code three times.
+    int lobe; float phi, cosTheta = 0.0f, sinTheta = 0.0f;
     if (r1 < s.clearcoat) {
+        lobe = 0;
         r1 /= s.clearcoat;
         const float a = mixf(0.1f, 0.001f, s.clearcoatGloss);
-        const float cosTheta = sqrtf((1.0f - a_powf(a * a, 1.0f - r2)) / (1.0f - a * a));
-        const float sinTheta = sqrtf(dmax(0.0f, 1.0f - (cosTheta * cosTheta)));
-        const float phi = r1 * kTwoPI;
-        F3 H = normalized(f3(a_cosf(phi) * sinTheta, a_sinf(phi) * sinTheta, cosTheta));
+        cosTheta = sqrtf((1.0f - a_powf(a * a, 1.0f - r2)) / (1.0f - a * a));
+        sinTheta = sqrtf(dmax(0.0f, 1.0f - (cosTheta * cosTheta)));
+        phi = r1 * kTwoPI;
+    } else {
+        r1 -= s.clearcoat;
+        r1 /= (1.0f - s.clearcoat);
+        if (r2 < s.csw) {
+            lobe = 1;
+            r2 /= s.csw;
+            const float a = dmax(0.001f, s.roughness);
+            cosTheta = sqrtf((1.0f - r2) / (1.0f + (a * a - 1.0f) * r2));
+            sinTheta = sqrtf(dmax(0.0f, 1.0f - (cosTheta * cosTheta)));
+            phi = r1 * kTwoPI;
+        } else {
+            lobe = 2;
+            r2 -= s.csw;
+            r2 /= (1.0f - s.csw);
+            phi = kTwoPI * r2;
+        }
+    }
+    float sin_p, cos_p;
+    a_sincosf(phi, sin_p, cos_p);
+    if (lobe < 2) {
+        F3 H = normalized(f3(cos_p * sinTheta, sin_p * sinTheta, cosTheta));
         H = H.x * T + H.y * B + H.z * N;
         if (dot(H, V) <= 0.0f) H = H * -1.0f;
         return reflect(neg(V), H);
     }
-    r1 -= s.clearcoat;
-    r1 /= (1.0f - s.clearcoat);
-    if (r2 < s.csw) {
-        r2 /= s.csw;
-        const float a = dmax(0.001f, s.roughness);
-        const float cosTheta = sqrtf((1.0f - r2) / (1.0f + (a * a - 1.0f) * r2));
-        const float sinTheta = sqrtf(dmax(0.0f, 1.0f - (cosTheta * cosTheta)));
-        const float phi = r1 * kTwoPI;
-        F3 H = normalized(f3(a_cosf(phi) * sinTheta, a_sinf(phi) * sinTheta, cosTheta));
-        H = H.x * T + H.y * B + H.z * N;
-        if (dot(H, V) <= 0.0f) H = H * -1.0f;
-        return reflect(neg(V), H);
-    }
-    r2 -= s.csw;
-    r2 /= (1.0f - s.csw);
     F3 d;
-    const float r = sqrtf(r1), phi = kTwoPI * r2;
-    d.x = r * a_cosf(phi); d.y = r * a_sinf(phi);
+    const float r = sqrtf(r1);
+    d.x = r * cos_p; d.y = r * sin_p;
     d.z = sqrtf(dmax(0.0f, 1.0f - d.x * d.x - d.y * d.y));
     return T * d.x + B * d.y + N * d.z;
 }
@@ -310,8 +325,8 @@ PT_DEV F3 ggx_sample(float roughness, float& probability, Rng& rng) {
     const float a = roughness * roughness;
     const float F = rng.U() * 0.99999f;
     const float theta = a_acosf(sqrtf((1.0f - F) / (F * (a * a - 1.0f) + 1.0f)));
-    float cosTheta = a_cosf(theta);
-    const float sinTheta = a_sinf(theta);
+    float cosTheta, sinTheta;
+    a_sincosf(theta, sinTheta, cosTheta);
     if (cosTheta < 0.0f) cosTheta = 0.0f;
     const float beta = rng.U() * kTwoPI;
     float bottom = (a * a - 1.0f) * cosTheta * cosTheta + 1.0f;
@@ -319,7 +334,9 @@ PT_DEV F3 ggx_sample(float roughness, float& probability, Rng& rng) {
     if (bottom <= 0.0f) bottom = 0.001f;
     probability = a * a * cosTheta * sinTheta * kInvPI / bottom;
     if (probability <= 0.0f) probability = 0.001f;
-    return f3(sinTheta * a_cosf(beta), sinTheta * a_sinf(beta), cosTheta);
+    float sin_b, cos_b;
+    a_sincosf(beta, sin_b, cos_b);
+    return f3(sinTheta * cos_b, sinTheta * sin_b, cosTheta);
 }
 PT_DEV F3 cook_torrance(F3 L, F3 V, F3 N, F3 albedo, float roughness, float metalness) {
     const F3 H = normalized(V + L);
