@@ -1,0 +1,109 @@
+"""Scene I/O: the XML / .model / OBJ loaders against the programmatic builders and against the
+reference loader's documented semantics (src/xmlload.cpp, include/meshbuilder.h).  CPU only."""
+import os
+
+import numpy as np
+import pytest
+
+from pathtracer_amd import capi, loaders, scenes
+from pathtracer_amd.scene import Plane
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SC = os.path.join(HERE, "golden", "scenes")
+ROOT = os.path.dirname(HERE)
+
+
+def _nodes(n, out):
+    out.append(n)
+    for c in n.children:
+        _nodes(c, out)
+    return out
+
+
+def test_cornell_xml_equals_builder():
+    """The fixture carries the data of the reference's assets/cornell.xml; scenes.cornell_c1 builds the same scene
+    through the object model.  Both must flatten to the same C-ABI description, bit for bit."""
+    a = loaders.LoadScene(os.path.join(SC, "cornell_c1.xml"), width=512, height=512)
+    b = scenes.cornell_c1(512, 512)
+    da, _ka = a.to_desc()
+    db, _kb = b.to_desc()
+    assert da.num_nodes == db.num_nodes == 3 and da.num_lights == db.num_lights == 1
+    for i in range(da.num_nodes):
+        na, nb = da.nodes[i], db.nodes[i]
+        for f in ("tm", "itm", "pos", "local_to_world"):
+            assert bytes(getattr(na, f)) == bytes(getattr(nb, f)), (i, f)
+        assert (na.parent, na.object_kind, na.light) == (nb.parent, nb.object_kind, nb.light)
+        # material order in the file differs from the builder's list: compare what the node resolves to
+        if na.material >= 0:
+            ma, mb = da.materials[na.material], db.materials[nb.material]
+            assert bytes(ma) == bytes(mb)
+    assert bytes(da.camera) == bytes(db.camera)
+    assert tuple(da.lights[0].intensity) == tuple(db.lights[0].intensity) == (np.float32(10.6),) * 3
+    # <diffuse> is not parsed by the Disney branch (xmlload.cpp:363-426): albedo stays 0.5
+    assert all(tuple(m.albedo) == (0.5, 0.5, 0.5) for m in a.materials)
+
+
+def test_nested_scene_semantics(monkeypatch):
+    monkeypatch.chdir(ROOT)                          # file names inside a scene are relative to the working directory
+    s = loaders.LoadScene(os.path.join(SC, "nested_models.xml"))
+    nodes = _nodes(s.rootNode, [])
+    names = [n.name for n in nodes]
+    assert names[:5] == ["root", "box", "WallBottom", "QuadLight", "quad.model"]
+    box = nodes[1]
+    assert box.obj is None and np.array_equal(box.pos, np.array([0, 0, 12], dtype=np.float32))
+    # ReadColor: (r,g,b) * value
+    red = [m for m in s.materials if m.name == "red"][0]
+    assert red.albedo == pytest.approx((0.5, 0.1, 0.1)) and red.kind == capi.MTL_STANDARD
+    assert red.roughness == pytest.approx((0.3, 0.3, 0.3))           # colour default (1,1,1) * value
+    assert s.env_color == pytest.approx((0.1, 0.15, 0.2))
+    gold = [m for m in s.materials if m.name == "gold"][0]
+    assert gold.kind == capi.MTL_DISNEY and gold.clearcoat == pytest.approx(0.5) and gold.clearcoat_gloss == pytest.approx(0.8)
+    assert gold.sheen_tint == pytest.approx(0.1) and gold.albedo_map is not None
+    assert gold.albedo_map.texture.kind == capi.TEX_CHECKER and gold.albedo_map.tm[0] == np.float32(0.25)
+    # three-token light
+    ql = nodes[3]
+    assert isinstance(ql.obj, Plane) and ql.light.intensity == pytest.approx((8.5, 8.0, 7.5))
+    # textmodel: comments and blank lines skipped, 2 triangles, non-uniform scale applied to the node
+    tm = nodes[4]
+    assert tm.obj.meshes[0].faces.shape == (2, 4) and tm.obj.meshes[0].vertices.shape == (4, 3)
+    assert np.array_equal(tm.obj.meshes[0].aabb, np.array([-1, 0, -1, 1, 2, -1], dtype=np.float32))
+    assert tuple(tm.tm[[0, 4, 8]]) == (2.0, 3.0, 4.0)
+    # model: the imported node hangs under the object's node, which carries transform and material
+    mnode = [n for n in nodes if n.name.endswith("teapot_lowpoly.obj") and n.obj is None][0]
+    assert len(mnode.children) == 1 and mnode.children[0].obj.meshes[0].faces.shape[0] == 240
+    assert mnode.children[0].GetMaterial() is gold
+    # camera
+    c = s.camera
+    assert (c.width, c.height, c.fov, c.dof) == (96, 64, 30.0, 0.5) and c.focaldist == pytest.approx(60.2)
+    d, _keep = s.to_desc()                            # flattens: planes, two models, one light
+    assert d.num_models == 2 and d.num_lights == 1 and d.num_meshes == 2
+
+
+def test_light_attribute_forms(tmp_path):
+    base = open(os.path.join(SC, "cornell_c1.xml")).read()
+    for text, want in (("10.6", (10.6,) * 3), ("1 2 3", (1.0, 2.0, 3.0)), ("  4   5 6 ", (4.0, 5.0, 6.0))):
+        p = tmp_path / "l.xml"
+        p.write_text(base.replace('light="10.6"', f'light="{text}"'))
+        s = loaders.LoadScene(str(p))
+        assert s.rootNode.children[0].light.intensity == pytest.approx(want)
+    p.write_text(base.replace('light="10.6"', 'light="1 2"'))
+    with pytest.raises(loaders.SceneFormatError):
+        loaders.LoadScene(str(p))
+
+
+def test_errors(tmp_path):
+    base = open(os.path.join(SC, "cornell_c1.xml")).read()
+    p = tmp_path / "e.xml"
+    p.write_text(base.replace('type="plane" name="Floor"', 'type="obj" name="Floor"'))
+    with pytest.raises(loaders.SceneFormatError):
+        loaders.LoadScene(str(p))
+    p.write_text(base.replace('type="disney" name="reflect"', 'type="blinn" name="reflect"'))
+    with pytest.raises(loaders.SceneFormatError):
+        loaders.LoadScene(str(p))
+    p.write_text(base.replace("<camera>", "<cam>").replace("</camera>", "</cam>"))
+    with pytest.raises(loaders.SceneFormatError):
+        loaders.LoadScene(str(p))
+    # an unknown material name leaves the node without material: flattening rejects object nodes without one
+    p.write_text(base.replace('material="reflect"', 'material="nosuch"'))
+    s = loaders.LoadScene(str(p))
+    assert s.rootNode.children[1].GetMaterial() is None
