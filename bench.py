@@ -7,9 +7,11 @@ Disney rough material + one rectangular area light, primary + secondary rays, 30
 One "step" = one sample per pixel of the whole frame through the full hot path
 (init -> {extend, shade, connect} x bounces -> resolve) with the scene resident in HBM.
 
-N GPUs: one process per GPU (torch.distributed, backend nccl == RCCL); the scene is replicated,
-GPU g renders sample indices g, g+N, ... of every pixel (weak scaling: per-GPU work fixed), and
-the per-GPU running means are combined by ONE RCCL reduce at the end of the timed region.
+N GPUs: one process per GPU (torch.distributed, backend nccl == RCCL); the scene is replicated and
+the work is split with no data-path collective (weak scaling: per-GPU work fixed) either by sample
+index (default: GPU g renders samples g, g+N, ... of every pixel) or by image tile (--split tile:
+GPU g renders N samples per step of the 64x64 tiles k with k % N == g).  The per-GPU running means
+are combined by ONE RCCL reduce at the end of the timed region.
 
 Prints ONE JSON line (rank 0).
 """
@@ -68,11 +70,11 @@ def cpu_baseline(scene, pt, args):
     x0, y0 = (args.width - cw) // 2, (args.height - ch) // 2
     prm = capi.make_params(args.width, args.height, seed=args.seed)
     t0 = time.perf_counter()
-    _, _, _, st = orc.render(prm, 1, rect=(x0, y0, x0 + cw, y0 + ch), threads=threads)
+    _, _, _, st = orc.render(prm, args.cpu_spp, rect=(x0, y0, x0 + cw, y0 + ch), threads=threads)
     dt = time.perf_counter() - t0
     rays = st["closest"] + st["shadow"]
     return {"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
-            "sample": f"centre crop {cw}x{ch} x 1 spp of the same frame ({rays} rays, {dt:.1f} s), reference-mode traversal",
+            "sample": f"centre crop {cw}x{ch} x {args.cpu_spp} spp of the same frame ({rays} rays, {dt:.1f} s), reference-mode traversal",
             "samples_per_s": st["samples"] / dt}
 
 
@@ -86,7 +88,9 @@ def main():
     ap.add_argument("--width", type=int, default=3840)
     ap.add_argument("--height", type=int, default=2160)
     ap.add_argument("--seed", type=int, default=0x5EED)
-    ap.add_argument("--cpu-crop", type=int, nargs=2, default=[1920, 1080])
+    ap.add_argument("--cpu-crop", type=int, nargs=2, default=[3840, 2160])
+    ap.add_argument("--cpu-spp", type=int, default=3)
+    ap.add_argument("--split", choices=["sample", "tile"], default="sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -111,8 +115,14 @@ def main():
 
     t0 = time.perf_counter()
     scene, workload = build_scene(args)
-    off, stride = distributed.rank_sample_split(rank, world)
-    pt = PathTracer(scene, device=device, seed=args.seed, sample_offset=off, sample_stride=stride)
+    if args.split == "tile":
+        ts, toff, tstride = distributed.rank_tile_split(rank, world, 64)
+        pt = PathTracer(scene, device=device, seed=args.seed, tile_size=ts, tile_offset=toff, tile_stride=tstride)
+        spp_step = world            # a rank owns 1/N of the pixels: N samples of each keep the per-GPU work fixed
+    else:
+        off, stride = distributed.rank_sample_split(rank, world)
+        pt = PathTracer(scene, device=device, seed=args.seed, sample_offset=off, sample_stride=stride)
+        spp_step = 1
     pt.Init(args.width, args.height)
     if rank == 0:
         log(f"scene + BVH + upload: {time.perf_counter() - t0:.1f} s")
@@ -124,7 +134,7 @@ def main():
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        pt.step(1)
+        pt.step(spp_step)
     pt.sync()
     pt.reset_stats()
     pt.set_profiling(events=True, count_work=False)     # HIP events around every launch, on the renderer's stream
@@ -132,7 +142,7 @@ def main():
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        pt.step(1)
+        pt.step(spp_step)
     pt.sync()
     if dist is not None:            # read-out: ONE RCCL reduce of (n*mean, n) per pixel, straight from the accumulators in HBM
         mean_t, cnt_t = distributed.accum_tensors(pt)
@@ -157,26 +167,34 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": workload, "triangles": int(pt.dscene.desc.meshes[0].num_faces) if pt.dscene.desc.num_meshes else 0,
                        "resolution": [args.width, args.height], "spp_per_step": 1, "max_bounces": 30,
-                       "split": "sample index g, g+N, ... per GPU; one RCCL reduce at the end"},
+                       "split": ("sample index g, g+N, ... per GPU" if args.split == "sample" else "64x64 image tiles k % N == g, N spp per step")
+                                + "; one RCCL reduce at the end"},
             "samples_per_pixel_per_s": samples_total / npix / dt,
             "rays_per_sample": rays_total / max(samples_total, 1.0),
             "kernel_ms": {"extend": st["extend_ms"], "shade": st["shade_ms"], "connect": st["connect_ms"], "other": st["other_ms"]},
         }
-    # ---- roofline of the dominant kernel (k_extend): algorithmic bytes / measured launch time
+    # ---- roofline of the dominant kernel (k_trace<closest>, the extend stage): algorithmic bytes / measured launch time
     if rank == 0 and not args.no_roofline:
         ext_ms, launches = st["extend_ms"], st["extend_launches"]
         closest = st["closest_rays"]
         pt.set_profiling(events=False, count_work=True)      # counting build, untimed
         pt.reset_stats()
-        pt.step(1)
+        pt.step(spp_step)
         pt.sync()
         cs = pt.stats()
         n_node = cs["bvh_node_visits"] / max(cs["closest_rays"], 1)
         n_tri = cs["bvh_tri_tests"] / max(cs["closest_rays"], 1)
         bytes_per_ray = NODE_BYTES * n_node + TRI_BYTES * n_tri + QUEUE_BYTES
         achieved = closest * bytes_per_ray / (ext_ms * 1e-3) / 1e9 if ext_ms > 0 else 0.0
-        out["roofline"] = {"bound": "hbm", "kernel": "k_extend", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+        # HBM traffic per launch from the PMC passes of this same command (tools/gpu_measure.sh; FETCH_SIZE and
+        # WRITE_SIZE in separate runs, corrected as MI355X_MICROARCH.md prescribes), committed under profiles/
+        traffic = None
+        tp = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(tp) and args.workload == "c4" and world == 1:
+            with open(tp) as f:
+                traffic = json.load(f).get("k_trace_closest_bytes_per_launch")
+        out["roofline"] = {"bound": "hbm", "kernel": "k_trace<closest> (extend)", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                            "bytes_per_ray": bytes_per_ray, "n_node_per_ray": n_node, "n_tri_per_ray": n_tri,
                            "launches": int(launches), "avg_launch_ms": ext_ms / max(launches, 1),
                            "avg_bytes_per_launch": closest * bytes_per_ray / max(launches, 1),

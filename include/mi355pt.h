@@ -173,6 +173,9 @@ typedef struct mi355pt_render_params {
     uint32_t sample_offset;     /* first sample index this renderer owns (multi-GPU)   */
     uint32_t sample_stride;     /* sample index stride (1 on one GPU, G on G GPUs)     */
     int32_t  device;            /* HIP device ordinal                                  */
+    uint32_t tile_size;         /* image-tile partition (multi-GPU): 0 = whole image;  */
+    uint32_t tile_offset;       /*   else tile k of the row-major grid of tile_size^2  */
+    uint32_t tile_stride;       /*   tiles is rendered iff k % tile_stride == tile_offset */
 } mi355pt_render_params;
 
 /* Per-renderer counters (SURVEY section 8d ray-counting rule: 1 per TraceNode call,

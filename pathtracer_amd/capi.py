@@ -79,7 +79,8 @@ class SceneDesc(C.Structure):
 
 class RenderParams(C.Structure):
     _fields_ = [("width", u32), ("height", u32), ("max_bounces", u32), ("rr_start", u32), ("seed", u32),
-                ("sample_offset", u32), ("sample_stride", u32), ("device", i32)]
+                ("sample_offset", u32), ("sample_stride", u32), ("device", i32),
+                ("tile_size", u32), ("tile_offset", u32), ("tile_stride", u32)]
 
 
 class Stats(C.Structure):
@@ -88,8 +89,10 @@ class Stats(C.Structure):
                 ("connect_ms", C.c_double), ("other_ms", C.c_double), ("extend_launches", u64), ("debug", u64 * 8)]
 
 
-def make_params(width, height, seed=0x5EED, max_bounces=30, rr_start=3, sample_offset=0, sample_stride=1, device=0):
-    return RenderParams(width, height, max_bounces, rr_start, seed, sample_offset, sample_stride, device)
+def make_params(width, height, seed=0x5EED, max_bounces=30, rr_start=3, sample_offset=0, sample_stride=1, device=0,
+                tile_size=0, tile_offset=0, tile_stride=1):
+    return RenderParams(width, height, max_bounces, rr_start, seed, sample_offset, sample_stride, device,
+                        tile_size, tile_offset, tile_stride)
 
 
 # Every symbol include/mi355pt.h declares (checked by tests/test_abi.py).

@@ -100,13 +100,14 @@ __device__ __forceinline__ uint32_t xcd_block(uint32_t b, uint32_t nb) {
 // ---------------------------------------------------------------------- init
 __global__ void __launch_bounds__(kBlock) k_init(DPaths P, Params prm, uint32_t n, uint32_t pix_base, uint32_t npix_chunk,
                                                  const uint32_t* cnt, uint32_t sample_offset, uint32_t sample_stride,
-                                                 const uint32_t* list_pix, const uint32_t* list_smp) {
+                                                 const uint32_t* list_pix, const uint32_t* list_smp, const uint32_t* own) {
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         uint32_t pixel, sample;
         if (list_pix) { pixel = list_pix[i]; sample = list_smp[i]; }
         else {
             const uint32_t s = i / npix_chunk;
             pixel = pix_base + (i - s * npix_chunk);
+            if (own) pixel = own[pixel];                 // tile split: the chunk indexes this renderer's pixel list
             sample = sample_offset + (cnt[pixel] + s) * sample_stride;
         }
         P.id[i] = make_uint4(pixel, sample, 2u, 0u);            // draws 0,1 = lens (utils.cpp:70,73)
@@ -689,9 +690,9 @@ __device__ __forceinline__ F3 finish_sample(F3 c, F3* linear) {
     return f3(a_powf(m.x, 0.4545f), a_powf(m.y, 0.4545f), a_powf(m.z, 0.4545f));
 }
 __global__ void __launch_bounds__(kBlock) k_resolve(DPaths P, float* mean, uint32_t* cnt, uint8_t* rgb8, uint32_t pix_base,
-                                                    uint32_t npix_chunk, uint32_t ns) {
+                                                    uint32_t npix_chunk, uint32_t ns, const uint32_t* own) {
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < npix_chunk; i += gridDim.x * blockDim.x) {
-        const uint32_t pixel = pix_base + i;
+        const uint32_t pixel = own ? own[pix_base + i] : pix_base + i;
         F3 c = f3(mean[3 * (size_t)pixel], mean[3 * (size_t)pixel + 1], mean[3 * (size_t)pixel + 2]);
         uint32_t n = cnt[pixel];
         for (uint32_t s = 0; s < ns; s++) {
@@ -804,6 +805,7 @@ struct mi355pt_render {
     hipStream_t stream = nullptr;
     std::vector<void*> allocs;
     float* mean = nullptr; uint32_t* cnt = nullptr; uint8_t* rgb8 = nullptr;
+    uint32_t* own = nullptr; size_t n_own = 0;       // tile split: the pixels this renderer renders (nullptr = all)
     bool profiling = false, count_work = false;
     struct Ev { hipEvent_t a, b; int kind; };
     std::vector<Ev> events;
@@ -1118,6 +1120,19 @@ int mi355pt_render_create(mi355pt_scene* scene, const mi355pt_render_params* par
     HIP_TRY(hipMemsetAsync(r->mean, 0, npix * 12, r->stream)); HIP_TRY(hipMemsetAsync(r->cnt, 0, npix * 4, r->stream));
     HIP_TRY(hipMemsetAsync(r->rgb8, 0, npix * 3, r->stream));
     HIP_TRY(hipStreamSynchronize(r->stream));
+    if (params->tile_size > 0 && params->tile_stride > 1) {
+        // image-tile partition (north_star multi-GPU): tile k of the row-major tile grid belongs to the renderer with
+        // k % tile_stride == tile_offset -- interleaved, like the reference's strided workers (pathtracer.cpp:66-109)
+        if (params->tile_offset >= params->tile_stride) return fail(MI355PT_ERR_INVALID, "tile_offset must be < tile_stride");
+        const uint32_t ts = params->tile_size, tx = (params->width + ts - 1) / ts;
+        std::vector<uint32_t> own;
+        for (uint32_t y = 0; y < params->height; y++)
+            for (uint32_t x = 0; x < params->width; x++)
+                if (((y / ts) * tx + x / ts) % params->tile_stride == params->tile_offset) own.push_back(y * params->width + x);
+        r->n_own = own.size();
+        HIP_TRY(dalloc((void**)&r->own, std::max<size_t>(own.size(), 1) * 4));
+        if (!own.empty()) HIP_TRY(hipMemcpy(r->own, own.data(), own.size() * 4, hipMemcpyHostToDevice));
+    }
     hipDeviceProp_t prop; HIP_TRY(hipGetDeviceProperties(&prop, scene->device));
     r->grid = prop.multiProcessorCount * 8;
     {   // persistent extend kernel: one wave per workgroup, LDS = stack of (tree depth + 4) dwords per lane + the wave's
@@ -1216,7 +1231,8 @@ int mi355pt_render_step(mi355pt_render* r, uint32_t spp) {
     if (!r) return fail(MI355PT_ERR_INVALID, "null renderer");
     HIP_TRY(hipSetDevice(r->scene->device));
     const mi355pt_render_params& p = r->prm;
-    const size_t npix = (size_t)p.width * p.height, cap = r->P.cap;
+    const size_t npix = r->own ? r->n_own : (size_t)p.width * p.height, cap = r->P.cap;
+    if (npix == 0) return MI355PT_OK;
     const size_t ppc = std::min(npix, cap);
     const size_t spc = ppc == npix ? std::max<size_t>(1, cap / npix) : 1;
     const Params kprm{p.seed, p.width, p.height, p.max_bounces, p.rr_start, r->stack_entries, r->node_lanes, r->owner_lanes};
@@ -1227,11 +1243,11 @@ int mi355pt_render_step(mi355pt_render* r, uint32_t spp) {
             const uint32_t n = np * ns;
             ev_begin(r, 3);
             hipLaunchKernelGGL(k_init, dim3(grid_for(r, n)), dim3(kBlock), 0, r->stream, r->P, kprm,
-                               n, (uint32_t)pix_base, np, r->cnt, p.sample_offset, p.sample_stride, (const uint32_t*)nullptr, (const uint32_t*)nullptr);
+                               n, (uint32_t)pix_base, np, r->cnt, p.sample_offset, p.sample_stride, (const uint32_t*)nullptr, (const uint32_t*)nullptr, (const uint32_t*)r->own);
             ev_end(r);
             if (int rc = run_paths(r, n)) return rc;
             ev_begin(r, 3);
-            hipLaunchKernelGGL(k_resolve, dim3(grid_for(r, np)), dim3(kBlock), 0, r->stream, r->P, r->mean, r->cnt, r->rgb8, (uint32_t)pix_base, np, ns);
+            hipLaunchKernelGGL(k_resolve, dim3(grid_for(r, np)), dim3(kBlock), 0, r->stream, r->P, r->mean, r->cnt, r->rgb8, (uint32_t)pix_base, np, ns, (const uint32_t*)r->own);
             ev_end(r);
         }
     }
@@ -1347,7 +1363,7 @@ int mi355pt_sample_radiance(mi355pt_render* r, const uint32_t* pixel, const uint
     const mi355pt_render_params& p = r->prm;
     const Params kprm{p.seed, p.width, p.height, p.max_bounces, p.rr_start, r->stack_entries, r->node_lanes, r->owner_lanes};
     hipLaunchKernelGGL(k_init, dim3(grid_for(r, count)), dim3(kBlock), 0, r->stream, r->P, kprm,
-                       count, 0u, 1u, (const uint32_t*)r->cnt, 0u, 1u, (const uint32_t*)dp, (const uint32_t*)ds);
+                       count, 0u, 1u, (const uint32_t*)r->cnt, 0u, 1u, (const uint32_t*)dp, (const uint32_t*)ds, (const uint32_t*)nullptr);
     int rc = run_paths(r, count);
     hipLaunchKernelGGL(k_gather, dim3(grid_for(r, count)), dim3(kBlock), 0, r->stream, r->P, count, dl, dm);
     hipError_t e = hipStreamSynchronize(r->stream);

@@ -1,8 +1,9 @@
 """Multi-GPU work split and read-out for the progressive renderer.
 
 Every (pixel, sample) is independent given the immutable scene (src/pathtracer.cpp:70-108),
-so the path shards with no data-path collective: the scene is replicated, rank g renders
-sample indices g, g+G, g+2G, ... of every pixel.  The reference averages tone-mapped
+so the path shards with no data-path collective: the scene is replicated and rank g renders
+either sample indices g, g+G, g+2G, ... of every pixel (sample split) or every sample of the
+image tiles k with k % G == g (tile split); a pixel a rank does not own has count 0 there.  The reference averages tone-mapped
 samples (pathtracer.cpp:86-90), so the per-pixel value is linear in the samples and the
 read-out is ONE exchange: sum_g n_g * mean_g and sum_g n_g, reduced to rank 0 (RCCL over
 xGMI when the tensors live in HBM; gloo in the CPU tests).
@@ -15,6 +16,24 @@ def rank_sample_split(rank, world):
     if not 0 <= rank < world:
         raise ValueError(f"rank {rank} outside world {world}")
     return rank, world
+
+
+def rank_tile_split(rank, world, tile_size=64):
+    """(tile_size, tile_offset, tile_stride) of a rank for the image-tile partition: tile k of the row-major grid
+    of tile_size x tile_size tiles goes to rank k % world -- interleaved, like the reference's strided workers
+    (src/pathtracer.cpp:66-109), so every rank gets a sample of the whole image and the load balances."""
+    if not 0 <= rank < world:
+        raise ValueError(f"rank {rank} outside world {world}")
+    return int(tile_size), rank, world
+
+
+def tile_owner_mask(width, height, tile_size, tile_offset, tile_stride):
+    """Boolean (height*width,) mask of the pixels a renderer with these tile parameters renders."""
+    if tile_size <= 0 or tile_stride <= 1:
+        return np.ones(width * height, dtype=bool)
+    y, x = np.divmod(np.arange(width * height, dtype=np.int64), width)
+    tx = (width + tile_size - 1) // tile_size
+    return ((y // tile_size) * tx + x // tile_size) % tile_stride == tile_offset
 
 
 class _DevArray:

@@ -51,11 +51,12 @@ class PathTracer:
     """Drop-in for the reference's PathTracer (same method names and meaning)."""
 
     def __init__(self, scene, device=0, seed=0x5EED, max_bounces=30, rr_start=3, sample_offset=0, sample_stride=1,
-                 spp_per_step=1):
+                 spp_per_step=1, tile_size=0, tile_offset=0, tile_stride=1):
         self.dscene = scene if isinstance(scene, DeviceScene) else DeviceScene(scene, device)
         self.lib = self.dscene.lib
         self._cfg = dict(seed=seed, max_bounces=max_bounces, rr_start=rr_start, sample_offset=sample_offset,
-                         sample_stride=sample_stride, device=self.dscene.device)
+                         sample_stride=sample_stride, device=self.dscene.device,
+                         tile_size=tile_size, tile_offset=tile_offset, tile_stride=tile_stride)
         self.spp_per_step = spp_per_step
         self.h = None
         self.outputing = threading.Event()      # the reference's global std::atomic<bool> outputing

@@ -31,9 +31,20 @@ def main():
         ok = bool(np.allclose(comb.numpy(), full, atol=2e-6)) and bool((total.numpy() == cf).all())
         d = np.abs(distributed.resolve_rgb8(comb.numpy()).astype(int) - rgb.astype(int))
         ok = ok and int(d.max()) <= 1
-        print("combined ok" if ok else "MISMATCH", flush=True)
     else:
         ok = out is None
+    # image-tile partition: each rank contributes only the pixels of its tiles (count 0 elsewhere); same read-out
+    ts, toff, tstride = distributed.rank_tile_split(rank, world, 8)
+    own = distributed.tile_owner_mask(w, h, ts, toff, tstride)
+    full, cf, rgb, _ = orc.render(capi.make_params(w, h, seed=11), spp_per_rank, threads=2)
+    tmean, tcnt = full * own[:, None], (cf * own).astype(np.int32)
+    out2 = distributed.combine_running_means(torch.from_numpy(tmean.astype(np.float32)), torch.from_numpy(tcnt), dist, 0)
+    if rank == 0:
+        comb2, total2 = out2
+        ok = ok and bool(np.allclose(comb2.numpy(), full, atol=2e-6)) and bool((total2.numpy() == cf).all())
+        print("combined ok" if ok else "MISMATCH", flush=True)
+    else:
+        ok = ok and out2 is None
     flag = torch.tensor([0 if ok else 1])
     dist.all_reduce(flag)
     dist.destroy_process_group()

@@ -45,3 +45,16 @@ def test_combine_single_process_is_weighted_mean():
     out, total = distributed.combine_running_means(mean, cnt)
     assert np.allclose(out.numpy(), mean.numpy(), atol=1e-6) and (total.numpy() == cnt.numpy()).all()
     assert distributed.resolve_rgb8(np.array([[0.999, 0.5, 1.0]], dtype=np.float32)).tolist() == [[254, 127, 255]]
+
+
+def test_tile_split_partitions_the_image():
+    w, h = 70, 50                                    # not a multiple of the tile size
+    for world in (1, 2, 3, 8):
+        owners = np.zeros(w * h, dtype=np.int32)
+        for r in range(world):
+            ts, off, stride = distributed.rank_tile_split(r, world, 16)
+            owners += distributed.tile_owner_mask(w, h, ts, off, stride)
+        assert (owners == 1).all()
+    m = distributed.tile_owner_mask(w, h, 16, 1, 2).reshape(h, w)
+    assert not m[0, 0] and m[0, 16] and m[0, 31] and not m[0, 32]      # tiles 0,1,2 of the first row
+    assert m[16, 0] == (((1 * 5 + 0) % 2) == 1)                         # 5 tiles per row
