@@ -41,7 +41,7 @@ extern "C" {
 /* object kinds (reference include/objects.h: Plane, Sphere; include/model.h: Model) */
 #define MI355PT_OBJ_NONE   0
 #define MI355PT_OBJ_PLANE  1
-#define MI355PT_OBJ_SPHERE 2   /* reserved: SURVEY section 8(f) "next"                */
+#define MI355PT_OBJ_SPHERE 2   /* unit sphere, src/objects.cpp:620-790                */
 #define MI355PT_OBJ_MODEL  3
 
 /* material kinds (reference include/disneyMaterial.h, include/standardMaterial.h)    */

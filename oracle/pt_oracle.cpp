@@ -452,10 +452,76 @@ bool PlaneIntersectRayCtx(const RayContext& rc, HitInfo& hInfo, int hitSide) {
     return true;
 }
 
+// ------------------------------------------------------------------ sphere
+// src/objects.cpp:620-628
+inline V3 SphereCalculateCoord(V3 p, float reverseLength) {
+    return v3((0.5f - atan2f(p.x, p.y) / (2.0f * PI)), (0.5f + asinf(p.z * reverseLength) / (PI)), 0.0f);
+}
+// src/objects.cpp:684-790 (unit sphere in object space; N is left un-normalised, Tangent / Bitangent stay zero)
+bool SphereIntersectRay(const Ray& ray, HitInfo& hInfo, int hitSide) {
+    float a = length_sq(ray.dir);
+    float b = 2 * dot(ray.p, ray.dir);
+    float c = length_sq(ray.p) - 1;
+    float delta = b * b - 4 * a * c;
+    if (delta < 0) return false;
+    if (delta == 0) {
+        float dist = -1.0f * b / (2.0f * a);
+        V3 intersectPoint = ray.p + ray.dir * dist;
+        if (dist < 0.0f) return false;
+        if (hitSide == HIT_FRONT || hitSide == HIT_FRONT_AND_BACK) {
+            if (dist < hInfo.z) {
+                hInfo.z = dist; hInfo.N = intersectPoint; hInfo.p = intersectPoint; hInfo.front = true;
+                hInfo.uvw = SphereCalculateCoord(intersectPoint, 1.0f);
+            }
+            return true;
+        }
+        return false;
+    }
+    float dist1 = (-1.0f * b - sqrtf(delta)) / (2.0f * a);
+    float dist2 = (-1.0f * b + sqrtf(delta)) / (2.0f * a);
+    V3 intersectPoint1 = ray.p + ray.dir * dist1;
+    V3 intersectPoint2 = ray.p + ray.dir * dist2;
+    if (dist1 < 0.0f) {
+        if (dist2 < 0.0f) return false;
+        if (hitSide == HIT_BACK || hitSide == HIT_FRONT_AND_BACK) {
+            if (dist2 < hInfo.z) {
+                hInfo.z = dist2; hInfo.N = -1.0f * intersectPoint2; hInfo.p = intersectPoint2; hInfo.front = false;
+                hInfo.uvw = SphereCalculateCoord(intersectPoint2, 1.0f);
+            }
+            return true;
+        }
+        return false;
+    }
+    if (hitSide == HIT_FRONT || hitSide == HIT_FRONT_AND_BACK) {
+        if (dist1 < hInfo.z) {
+            hInfo.z = dist1; hInfo.N = intersectPoint1; hInfo.p = intersectPoint1; hInfo.front = true;
+            hInfo.uvw = SphereCalculateCoord(intersectPoint1, 1.0f);
+        }
+        return true;
+    }
+    return false;
+}
+// src/objects.cpp:630-682
+bool SphereIntersectRayCtx(const RayContext& rc, HitInfo& hInfo, int hitSide) {
+    if (!SphereIntersectRay(rc.cameraRay, hInfo, hitSide)) return false;
+    if (!rc.hasDiff) { hInfo.duvw[0] = v3(0, 0, 0); hInfo.duvw[1] = v3(0, 0, 0); return true; }
+    const V3 N = normalized(hInfo.N);
+    const float zRight = dot(rc.rightRay.p - hInfo.p, N);
+    const float tRight = -1.0f * zRight / dot(rc.rightRay.dir, N);
+    const V3 pRight = rc.rightRay.p + tRight * rc.rightRay.dir;
+    const float zTop = dot(rc.topRay.p - hInfo.p, N);
+    const float tTop = -1.0f * zTop / dot(rc.topRay.dir, N);
+    const V3 pTop = rc.topRay.p + tTop * rc.topRay.dir;
+    hInfo.duvw[0] = (SphereCalculateCoord(pRight, 1.0f / length(pRight)) - hInfo.uvw) / rc.delta;
+    hInfo.duvw[1] = (SphereCalculateCoord(pTop, 1.0f / length(pTop)) - hInfo.uvw) / rc.delta;
+    return true;
+}
+
 template <bool CTX>
 bool ObjectIntersectRay(const Scene& sc, const mi355pt_node& nd, const RayContext& rc, HitInfo& h, int side) {
     switch (nd.object_kind) {
     case MI355PT_OBJ_PLANE: return CTX ? PlaneIntersectRayCtx(rc, h, side) : PlaneIntersectRay(rc.cameraRay, h, side);
+    case MI355PT_OBJ_SPHERE: return CTX ? SphereIntersectRayCtx(rc, h, side) : SphereIntersectRay(rc.cameraRay, h, side);
     case MI355PT_OBJ_MODEL: return ModelIntersectRay<CTX>(sc, sc.models[nd.object_index], rc, h, side);
     default: return false;
     }

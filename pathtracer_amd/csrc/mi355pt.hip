@@ -296,11 +296,13 @@ __global__ void __launch_bounds__(kExtBlock) k_trace(DScene S, DPaths P, Params 
                         const uint32_t rii = __float_as_uint(h1.x);
                         if (ANY && rii == linst) { rec = nexti; continue; }           // the light's own object is not an occluder
                         const Ray lr = rec_ray(S, R, clen, rii, wr);
-                        if (kind == MI355PT_OBJ_PLANE) {
+                        if (kind != MI355PT_OBJ_MODEL) {                  // analytic objects: Plane, Sphere (objects.cpp:474-790)
                             float t; bool front; F3 Pp;
+                            const int side = ANY ? SIDE_FRONT : SIDE_BOTH;
+                            const bool hit = kind == MI355PT_OBJ_PLANE ? plane_hit(lr.p, lr.d, side, t, front, Pp) : sphere_hit(lr.p, lr.d, side, t, front, Pp);
                             if (ANY) {
-                                if (plane_hit(lr.p, lr.d, SIDE_FRONT, t, front, Pp) && t < bound) { P.vis[slot] = 1; state = LS_IDLE; break; }
-                            } else if (plane_hit(lr.p, lr.d, SIDE_BOTH, t, front, Pp) && t < best_t) { best_t = t; best_inst = (int)rii; best_mesh = -1; best_slot = 0; }
+                                if (hit && t < bound) { P.vis[slot] = 1; state = LS_IDLE; break; }
+                            } else if (hit && t < best_t) { best_t = t; best_inst = (int)rii; best_mesh = -1; best_slot = 0; }
                             rec = nexti;
                             continue;
                         }
@@ -885,7 +887,7 @@ int mi355pt_scene_create(const mi355pt_scene_desc* desc, int32_t device, mi355pt
         memcpy(d.l2w, s.local_to_world, sizeof(d.l2w));
         d.material = s.material; d.light = s.light; d.pad0 = d.pad1 = 0;
         if (s.object_kind == MI355PT_OBJ_NONE) continue;
-        if (s.object_kind != MI355PT_OBJ_PLANE && s.object_kind != MI355PT_OBJ_MODEL) return fail(MI355PT_ERR_UNSUPPORTED, "object kind not supported (Sphere is a later row)");
+        if (s.object_kind != MI355PT_OBJ_PLANE && s.object_kind != MI355PT_OBJ_SPHERE && s.object_kind != MI355PT_OBJ_MODEL) return fail(MI355PT_ERR_UNSUPPORTED, "unknown object kind");
         if (s.material < 0 || (uint32_t)s.material >= desc->num_materials) return fail(MI355PT_ERR_INVALID, "object node without material");
         if (s.object_kind == MI355PT_OBJ_MODEL && (s.object_index < 0 || (uint32_t)s.object_index >= desc->num_models)) return fail(MI355PT_ERR_INVALID, "bad model index");
         DInst in{}; in.node = (int)i; in.kind = s.object_kind; in.model = s.object_index;

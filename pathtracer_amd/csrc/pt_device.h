@@ -349,4 +349,33 @@ PT_DEV bool plane_hit(F3 o, F3 d, int side, float& t, bool& front, F3& P) {
     return true;
 }
 
+// ------------------------------------------------------------------ sphere (objects.cpp:684-790)
+// Unit sphere in object space.  Two roots: the near one is a front hit; when it lies behind the origin the far one
+// is a back hit; a double root (delta == 0) is a front hit.  Same expression trees as the reference.
+PT_DEV bool sphere_hit(F3 o, F3 d, int side, float& t, bool& front, F3& P) {
+    const float a = len2(d);
+    const float b = 2 * dot(o, d);
+    const float c = len2(o) - 1;
+    const float delta = b * b - 4 * a * c;
+    if (delta < 0) return false;
+    if (delta == 0) {
+        const float dist = -1.0f * b / (2.0f * a);
+        if (dist < 0.0f) return false;
+        if (!(side & SIDE_FRONT)) return false;
+        t = dist; front = true; P = o + d * dist;
+        return true;
+    }
+    const float dist1 = (-1.0f * b - sqrtf(delta)) / (2.0f * a);
+    const float dist2 = (-1.0f * b + sqrtf(delta)) / (2.0f * a);
+    if (dist1 < 0.0f) {
+        if (dist2 < 0.0f) return false;
+        if (!(side & SIDE_BACK)) return false;
+        t = dist2; front = false; P = o + d * dist2;
+        return true;
+    }
+    if (!(side & SIDE_FRONT)) return false;
+    t = dist1; front = true; P = o + d * dist1;
+    return true;
+}
+
 }  // namespace ptd

@@ -79,6 +79,27 @@ PT_DEV void surf_plane(const Ray& r, bool hasDiff, const Ray& rr, const Ray& tr,
         h.du1 = (plane_tex(pT) - h.uvw) / 1.0f;
     } else { h.du0 = f3(0, 0, 0); h.du1 = f3(0, 0, 0); }
 }
+// Sphere::IntersectRay (objects.cpp:620-790): N = the hit point (un-normalised, negated on the back side), Tangent and
+// Bitangent stay at HitInfo::Init's zero, uvw = latitude / longitude of the hit point
+PT_DEV F3 sphere_tex(F3 p, float reverseLength) {
+    return f3(0.5f - a_atan2f(p.x, p.y) / (2.0f * kPI), 0.5f + a_asinf(p.z * reverseLength) / kPI, 0.0f);
+}
+PT_DEV void surf_sphere(const Ray& r, bool hasDiff, const Ray& rr, const Ray& tr, Surf& h) {
+    float t; bool front; F3 P;
+    sphere_hit(r.p, r.d, SIDE_BOTH, t, front, P);
+    h.front = front; h.N = front ? P : -1.0f * P; h.p = P; h.z = t;
+    h.T = f3(0, 0, 0); h.B = f3(0, 0, 0);
+    h.uvw = sphere_tex(P, 1.0f);
+    if (hasDiff) {
+        const F3 N = normalized(h.N);
+        const float tR = -1.0f * dot(rr.p - h.p, N) / dot(rr.d, N);
+        const F3 pR = rr.p + tR * rr.d;
+        const float tT = -1.0f * dot(tr.p - h.p, N) / dot(tr.d, N);
+        const F3 pT = tr.p + tT * tr.d;
+        h.du0 = (sphere_tex(pR, 1.0f / len(pR)) - h.uvw) / 1.0f;
+        h.du1 = (sphere_tex(pT, 1.0f / len(pT)) - h.uvw) / 1.0f;
+    } else { h.du0 = f3(0, 0, 0); h.du1 = f3(0, 0, 0); }
+}
 // FromNodeCoords up the chain (node.h:195-201), as TraceNode applies it level by level
 PT_DEV void surf_to_world(const DScene& S, const DInst& in, Surf& h) {
     for (int i = in.chain_len - 1; i >= 0; i--) {
@@ -100,6 +121,7 @@ PT_DEV void surf_from_hit(const DScene& S, const HitRec& hr, const Ray& wr, bool
         if (hasDiff) { rr = to_node(n, rr); tr = to_node(n, tr); }
     }
     if (in.kind == MI355PT_OBJ_PLANE) surf_plane(r, hasDiff, rr, tr, h);
+    else if (in.kind == MI355PT_OBJ_SPHERE) surf_sphere(r, hasDiff, rr, tr, h);
     else surf_triangle(S, S.meshes[S.models[in.model].first_mesh + hr.mesh], hr.slot, r, hasDiff, rr, tr, h);
     surf_to_world(S, in, h);
     h.node = in.node;

@@ -20,15 +20,15 @@ not part of this repo:
     per distinct (v, vt, vn) triple.  Triangle counts match the survey's probe of the reference importer for
     the shipped meshes (teapot 6 320, teapot_lowpoly 240, cat 2 082); vertex order may differ -- "parity
     unpinned" for anything that depends on it (nothing in the renderer does: hits are reported by face);
-  * `type="sphere"`, `type="obj"` objects and `type="blinn"` materials raise: the reference has no loader
-    branch for the last two (src/xmlload.cpp:228-256, 314-431) and Sphere is a later row of SURVEY 8f.
+  * `type="obj"` objects and `type="blinn"` materials raise: the reference has no loader branch for them either
+    (src/xmlload.cpp:228-256, 314-431).
 """
 import os
 import xml.etree.ElementTree as ET
 
 import numpy as np
 
-from .scene import (Camera, F, LightComponent, Mesh, Model, MtlDisney, MtlStandard, Node, Plane, Scene, TextureChecker,
+from .scene import (Camera, F, LightComponent, Mesh, Model, MtlDisney, MtlStandard, Node, Plane, Scene, Sphere, TextureChecker,
                     TextureFile, TextureMap, load_obj)
 
 
@@ -185,6 +185,8 @@ def _load_node(parent, el, pending, roots):
     typ = el.get("type")
     if typ == "plane":
         node.obj = Plane()
+    elif typ == "sphere":
+        node.obj = Sphere()
     elif typ == "model":
         node.AppendChild(LoadModel(_resolve(el.get("name") or "", roots), node.light))
     elif typ == "textmodel":

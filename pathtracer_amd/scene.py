@@ -155,6 +155,11 @@ class Plane:
     kind = capi.OBJ_PLANE
 
 
+class Sphere:
+    """reference src/objects.cpp:620-790: the unit sphere in object space."""
+    kind = capi.OBJ_SPHERE
+
+
 class Mesh:
     """reference include/mesh.h: vertices/normals/textureCoords per vertex, faces (i0,i1,i2,faceId)."""
 

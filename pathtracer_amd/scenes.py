@@ -9,8 +9,8 @@ import os
 
 import numpy as np
 
-from .scene import (Camera, LightComponent, Mesh, Model, MtlDisney, MtlStandard, Node, Plane, Scene,
-                    TextureFile, TextureMap, load_obj, F)
+from .scene import (Camera, LightComponent, Mesh, Model, MtlDisney, MtlStandard, Node, Plane, Scene, Sphere,
+                    TextureChecker, TextureFile, TextureMap, load_obj, F)
 
 ASSETS = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "assets")
 
@@ -59,6 +59,24 @@ def cornell_c3(width=3840, height=2160, dof=0.5):
     pos, target = np.array([0, -60, 16], dtype=F), np.array([0, 0, 11], dtype=F)
     fd = float(np.sqrt(np.sum((target - pos).astype(np.float64) ** 2)))
     s.camera = Camera(pos, target, (0, 0, 1), fov=30.0, focaldist=fd, dof=dof, width=width, height=height)
+    return s
+
+
+def cornell_spheres(width=512, height=512):
+    """The reference's assets/cornell1.xml as shipped: the Cornell walls of C3 plus two unit spheres
+    (`type="sphere"`, scaled / rotated / translated nodes), one Disney with a checker albedo, one Cook-Torrance."""
+    s = cornell_c3(width, height, dof=0.0)
+    chk = TextureMap(TextureChecker((0.9, 0.9, 0.9), (0.2, 0.3, 0.8)))
+    chk.Scale(0.125)
+    m2 = MtlDisney("mtl2", albedo=(1.0, 1.0, 1.0), roughness=np.float32(0.25), metalness=np.float32(0.3), specular=0.6, clearcoat=0.4,
+                   clearcoat_gloss=0.7)
+    m2.albedo_map = chk
+    m3 = MtlStandard("mtl3", albedo=(0.9, 0.6, 0.2), roughness=0.2, metalness=1.0)
+    s.materials += [m2, m3]
+    a = s.rootNode.AppendChild(Node("sphere2", Sphere(), m2))
+    a.Scale(4.5); a.Rotate((0, 1, 0), 30.0); a.Translate((8, -6, 4.5))
+    b = s.rootNode.AppendChild(Node("sphere3", Sphere(), m3))
+    b.Scale(3.0, 3.0, 4.0); b.Translate((-7, 2, 4.0))
     return s
 
 

@@ -31,6 +31,7 @@ def small_scenes():
         "teapot_cornell": (teapot_cornell, 96, 72),
         "grid_small": (grid_small, 128, 72),
         "textured_c2": (textured, 96, 54),
+        "cornell_spheres": (lambda w, h: scenes.cornell_spheres(w, h), 96, 72),
     }
 
 

@@ -207,3 +207,23 @@ def test_sample_offset_stride_partition_the_samples():
     _, mp = orc.sample_radiance(capi.make_params(w, h, seed=5), np.arange(w * h, dtype=np.uint32), np.full(w * h, 3, dtype=np.uint32))
     one = orc.render(capi.make_params(w, h, seed=5, sample_offset=3, sample_stride=2), 1, threads=1)[0]
     assert np.array_equal(one.view(np.uint32), mp.view(np.uint32))
+
+
+def test_sphere_known_answers():
+    """Sphere::IntersectRay (src/objects.cpp:684-790) on an untransformed unit sphere: near root in front = front hit,
+    origin inside = back hit at the far root, miss, and a sphere behind the origin is transparent."""
+    from oracle.binding import OracleScene
+    from pathtracer_amd import scene as sc
+    s = sc.Scene()
+    m = sc.MtlDisney("m")
+    s.materials = [m]
+    s.rootNode.AppendChild(sc.Node("ball", sc.Sphere(), m))
+    s.camera = sc.Camera((0, -5, 0), (0, 0, 0), (0, 0, 1), width=8, height=8)
+    orc = OracleScene(s)
+    o = np.array([[0, 0, -3], [0, 0, 0], [0, 0, 3], [2, 0, -3], [0.5, 0, -3]], dtype=np.float32)
+    d = np.array([[0, 0, 1], [0, 0, 1], [0, 0, 1], [0, 0, 1], [0, 0, 2]], dtype=np.float32)
+    node, mesh, face, t = orc.trace_rays(o, d)
+    assert node.tolist() == [1, 1, -1, -1, 1] and (mesh == -1).all() and (face == -1).all()
+    assert t[0] == np.float32(2.0) and t[1] == np.float32(1.0)
+    # unnormalised direction: t is in units of |dir| (the reference never renormalises in object space)
+    assert abs(float(t[4]) - (3.0 - np.sqrt(0.75)) / 2.0) < 1e-6
