@@ -137,8 +137,8 @@ def _read_texture(el, roots, cache):
     else:
         if name not in cache:
             p = _resolve(name, roots)
-            if not p.lower().endswith(".png"):
-                raise SceneFormatError(f"{name}: only 8-bit PNG textures are decoded here (the reference uses stb_image)")
+            if not p.lower().endswith((".png", ".hdr")):
+                raise SceneFormatError(f"{name}: only 8-bit PNG and Radiance .hdr textures are decoded here (the reference uses stb_image)")
             cache[name] = TextureFile(path=p)
         tex = cache[name]
     m = TextureMap(tex)

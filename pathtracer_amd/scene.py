@@ -210,7 +210,7 @@ class Model:
 class TextureFile:
     def __init__(self, data=None, path=None):
         if data is None:
-            data = load_png_rgb8(path)
+            data = load_hdr(path) if path.lower().endswith(".hdr") else load_png_rgb8(path)
         self.data = np.ascontiguousarray(data)          # (h, w, 3), rows as after the reference's flip
         self.kind = capi.TEX_RGB32F if self.data.dtype == np.float32 else capi.TEX_RGB8
         self.height, self.width = self.data.shape[:2]
@@ -516,6 +516,53 @@ def load_png_rgb8(path):
         img = np.repeat(img[:, :, :1], 3, axis=2)
     elif ch == 4:
         img = img[:, :, :3]
+    return np.ascontiguousarray(img[::-1])
+
+
+def load_hdr(path):
+    """Radiance .hdr (RGBE, flat or new-style RLE scanlines) -> (h, w, 3) float32, flipped vertically like
+    src/texture.cpp:81-83.  Component value = mantissa * 2^(e - 136), 0 when e == 0 (what stbi_loadf returns)."""
+    with open(path, "rb") as f:
+        b = f.read()
+    if not (b.startswith(b"#?RADIANCE") or b.startswith(b"#?RGBE")):
+        raise ValueError(f"{path}: not a Radiance HDR file")
+    pos = 0
+    fmt_ok = False
+    while True:
+        end = b.index(b"\n", pos)
+        line = b[pos:end]
+        pos = end + 1
+        if line.startswith(b"FORMAT=32-bit_rle_rgbe"):
+            fmt_ok = True
+        if line == b"":
+            break
+    end = b.index(b"\n", pos)
+    tok = b[pos:end].split()
+    pos = end + 1
+    if not fmt_ok or len(tok) != 4 or tok[0] != b"-Y" or tok[2] != b"+X":
+        raise ValueError(f"{path}: unsupported HDR layout")
+    h, w = int(tok[1]), int(tok[3])
+    rgbe = np.zeros((h, w, 4), dtype=np.uint8)
+    for y in range(h):
+        if 8 <= w < 32768 and b[pos] == 2 and b[pos + 1] == 2 and not (b[pos + 2] & 0x80):
+            if ((b[pos + 2] << 8) | b[pos + 3]) != w:
+                raise ValueError(f"{path}: corrupt scanline")
+            pos += 4
+            for c in range(4):
+                x = 0
+                while x < w:
+                    n = b[pos]; pos += 1
+                    if n > 128:
+                        n -= 128
+                        rgbe[y, x:x + n, c] = b[pos]; pos += 1
+                    else:
+                        rgbe[y, x:x + n, c] = np.frombuffer(b, dtype=np.uint8, count=n, offset=pos); pos += n
+                    x += n
+        else:
+            rgbe[y] = np.frombuffer(b, dtype=np.uint8, count=4 * w, offset=pos).reshape(w, 4); pos += 4 * w
+    e = rgbe[:, :, 3].astype(np.int32)
+    scale = np.where(e > 0, np.ldexp(np.float32(1.0), e - 136), np.float32(0.0)).astype(F)
+    img = (rgbe[:, :, :3].astype(F) * scale[:, :, None]).astype(F)
     return np.ascontiguousarray(img[::-1])
 
 

@@ -80,6 +80,32 @@ def cornell_spheres(width=512, height=512):
     return s
 
 
+def env_sphere(width=256, height=192):
+    """Environment-lit scene (reference include/scene.h:292-304, render.h:124-128): a floor, a small area light, a
+    mirror-like and a rough sphere under a float lat-long environment map (seeded synthetic sky, HDR range)."""
+    s = Scene()
+    rng = np.random.default_rng(21)
+    hh, ww = 32, 64
+    v = np.linspace(0.0, 1.0, hh, dtype=F)[:, None, None]
+    sky = (np.array([0.3, 0.5, 1.0], dtype=F) * v * 2.0 + np.array([0.6, 0.5, 0.4], dtype=F) * (1.0 - v)).astype(F)
+    sky = np.broadcast_to(sky, (hh, ww, 3)).copy()
+    sky += (rng.random((hh, ww, 3)) * 0.2).astype(F)
+    sky[hh * 3 // 4, ww // 3] = (60.0, 50.0, 40.0)                 # a "sun" texel
+    s.env_color = (1.0, 1.0, 1.0)
+    s.env_map = TextureMap(TextureFile(data=sky.astype(F)))
+    m_floor = MtlDisney("floor", albedo=(0.6, 0.6, 0.6), roughness=0.8)
+    m_a = MtlStandard("chrome", albedo=(0.95, 0.95, 0.95), roughness=0.05, metalness=1.0)
+    m_b = MtlDisney("rough", albedo=(0.8, 0.3, 0.2), roughness=0.7, sheen=0.5)
+    m_l = MtlDisney("light", roughness=1.0)
+    s.materials = [m_floor, m_a, m_b, m_l]
+    s.rootNode.AppendChild(_plane("Floor", m_floor, 40.0))
+    s.rootNode.AppendChild(_plane("QuadLight", m_l, 2.0, ((1, 0, 0), 180.0), (0, 0, 14), light=6.0))
+    a = s.rootNode.AppendChild(Node("a", Sphere(), m_a)); a.Scale(3.0); a.Translate((-3.5, 0, 3.0))
+    b = s.rootNode.AppendChild(Node("b", Sphere(), m_b)); b.Scale(2.0); b.Translate((3.5, -2, 2.0))
+    s.camera = Camera((0, -22, 8), (0, 0, 2.5), (0, 0, 1), fov=35.0, width=width, height=height)
+    return s
+
+
 def synthetic_texture(seed, size=1024, kind="albedo"):
     """Seeded stand-in for the reference's 1024^2 rock/brick maps (same shape and dtype)."""
     rng = np.random.default_rng(seed)

@@ -32,6 +32,7 @@ def small_scenes():
         "grid_small": (grid_small, 128, 72),
         "textured_c2": (textured, 96, 54),
         "cornell_spheres": (lambda w, h: scenes.cornell_spheres(w, h), 96, 72),
+        "env_sphere": (lambda w, h: scenes.env_sphere(w, h), 96, 72),
     }
 
 

@@ -107,3 +107,33 @@ def test_errors(tmp_path):
     p.write_text(base.replace('material="reflect"', 'material="nosuch"'))
     s = loaders.LoadScene(str(p))
     assert s.rootNode.children[1].GetMaterial() is None
+
+
+def test_hdr_decoder_rle_and_flat(tmp_path):
+    """Radiance RGBE: an RLE-coded and a flat file of the same pixels decode to mantissa * 2^(e-136), rows flipped."""
+    from pathtracer_amd.scene import load_hdr
+    w, h = 16, 3
+    rng = np.random.default_rng(5)
+    rgbe = rng.integers(0, 256, (h, w, 4), dtype=np.uint8)
+    rgbe[0, :, 3] = 130                                  # a run in the exponent channel
+    rgbe[1, 4, 3] = 0                                    # e == 0 -> black
+    head = b"#?RADIANCE\nFORMAT=32-bit_rle_rgbe\n\n-Y 3 +X 16\n"
+    flat = tmp_path / "flat.hdr"
+    flat.write_bytes(head + rgbe.tobytes())
+    body = b""
+    for y in range(h):
+        body += bytes([2, 2, 0, w])
+        for c in range(4):
+            row = rgbe[y, :, c]
+            if (row == row[0]).all():
+                body += bytes([128 + w, int(row[0])])
+            else:
+                body += bytes([w]) + row.tobytes()
+    rle = tmp_path / "rle.hdr"
+    rle.write_bytes(head + body)
+    a, b = load_hdr(str(flat)), load_hdr(str(rle))
+    e = rgbe[::-1, :, 3].astype(np.int32)
+    want = rgbe[::-1, :, :3].astype(np.float32) * np.where(e > 0, np.ldexp(np.float32(1.0), e - 136), 0.0).astype(np.float32)[:, :, None]
+    assert a.dtype == np.float32 and a.shape == (h, w, 3)
+    assert np.array_equal(a, want) and np.array_equal(b, want)
+    assert not a[1, 4].any()                             # flipped row 1 is still row 1 of 3
