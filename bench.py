@@ -46,6 +46,8 @@ def build_scene(args):
         return scenes.textured_c2(args.width, args.height), "C2 teapot.obj + cat.obj textured Disney"
     if args.workload == "c3":
         return scenes.cornell_c3(args.width, args.height), "C3 Cook-Torrance Cornell + DOF"
+    if args.workload == "c5":
+        return scenes.soup_c5(args.tris, args.width, args.height), f"C5 randomized triangle soup, {args.tris} triangles"
     raise SystemExit("unknown workload")
 
 
@@ -85,6 +87,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="c4")
     ap.add_argument("--grid", type=int, nargs=2, default=[205, 204])
+    ap.add_argument("--tris", type=int, default=100_000_000, help="triangle count of the c5 soup")
     ap.add_argument("--width", type=int, default=3840)
     ap.add_argument("--height", type=int, default=2160)
     ap.add_argument("--seed", type=int, default=0x5EED)
