@@ -105,11 +105,13 @@ def main():
         log(f"warning: WORLD_SIZE={world} but --gpus {args.gpus}")
     import torch
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("BENCH_FORCE_DIST"):     # BENCH_FORCE_DIST: rehearse the N>1 read-out path on one GPU
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     device = local_rank if world > 1 else 0
+    if dist is not None and world == 1:
+        log("rehearsing the distributed read-out with world size 1")
 
     from pathtracer_amd import PathTracer, capi, distributed
     lib = capi.load_library()
@@ -139,6 +141,10 @@ def main():
     for _ in range(args.warmup):
         pt.step(spp_step)
     pt.sync()
+    if dist is not None and args.warmup > 0:     # the read-out is part of a step's work: warm it up too (RCCL communicator, torch kernels)
+        mean_t, cnt_t = distributed.accum_tensors(pt)
+        distributed.combine_running_means(mean_t, cnt_t, dist, 0)
+        torch.cuda.synchronize()
     pt.reset_stats()
     pt.set_profiling(events=True, count_work=False)     # HIP events around every launch, on the renderer's stream
     npix = args.width * args.height
