@@ -25,6 +25,32 @@ def small_scenes():
     def textured(w, h):
         return scenes.textured_c2(w, h, tex_size=256)
 
+    def stress(w, h):
+        """Layout corner cases in one scene: a node chain deeper than the walk record's inline levels, a model of three
+        meshes (a 2-triangle mesh, a mesh of 37 coincident triangles -> one large leaf cut into chain records, a teapot),
+        more objects than the LDS record cache holds, a sphere nested under scaled nodes."""
+        s = scenes.cornell_c3(w, h, dof=0.0)
+        m = scene.MtlDisney("st", albedo=(0.8, 0.7, 0.6), roughness=np.float32(0.4), metalness=np.float32(0.1), specular=0.4)
+        s.materials.append(m)
+        quad = scene.Mesh(np.array([[3, 0, -1], [3, 0, 3], [6, 0, 3], [6, 0, -1]], dtype=np.float32),
+                          np.tile(np.array([[0, 0, 1]], dtype=np.float32), (4, 1)),
+                          np.array([[0, 0, 0], [1, 0, 0], [1, 1, 0], [0, 1, 0]], dtype=np.float32), np.array([[0, 1, 2], [0, 2, 3]]))
+        k = 37
+        tv = np.tile(np.array([[-6, 0, 0], [-3, 0.5, 0], [-6, 0.5, 3]], dtype=np.float32), (k, 1))
+        pile = scene.Mesh(tv, np.tile(np.array([[0, 0, 1]], dtype=np.float32), (3 * k, 1)),
+                          np.tile(np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0]], dtype=np.float32), (k, 1)), np.arange(3 * k).reshape(k, 3))
+        tp = scene.load_obj(os.path.join(ASSETS, "teapot_lowpoly.obj"))
+        tp = scene.Mesh((tp.vertices * np.float32(0.12)).astype(np.float32), tp.normals, tp.uvw, tp.faces[:, :3])      # ~4 units wide
+        chain = s.rootNode
+        for lvl in range(5):                                       # root + 5 + the object's node = 7 levels
+            chain = chain.AppendChild(scene.Node(f"lvl{lvl}"))
+            chain.Scale(1.0 + 0.03 * lvl, 1.0, 1.0 - 0.02 * lvl); chain.Rotate((0, 0, 1), 2.0 * (lvl + 1)); chain.Translate((0.3 * lvl, -0.2 * lvl, 0.1))
+        mm = chain.AppendChild(scene.Node("multi", scene.Model([quad, pile, tp]), m))
+        mm.Scale(1.5); mm.Translate((-2, -12, 8))
+        ball = chain.AppendChild(scene.Node("ball", scene.Sphere(), m))
+        ball.Scale(2.0, 1.5, 2.5); ball.Translate((-6, -14, 14))
+        return s
+
     return {
         "cornell_c1": (lambda w, h: scenes.cornell_c1(w, h), 96, 96),
         "cornell_c3_dof": (lambda w, h: scenes.cornell_c3(w, h, dof=0.5), 96, 64),
@@ -33,6 +59,7 @@ def small_scenes():
         "textured_c2": (textured, 96, 54),
         "cornell_spheres": (lambda w, h: scenes.cornell_spheres(w, h), 96, 72),
         "env_sphere": (lambda w, h: scenes.env_sphere(w, h), 96, 72),
+        "stress_layout": (stress, 96, 72),
     }
 
 

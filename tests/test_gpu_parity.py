@@ -154,7 +154,7 @@ def test_errors_are_loud(built):
     assert pt.lib.mi355pt_render_create(pt.dscene.h, C.byref(bad), C.byref(hnd)) == -1
 
 
-@pytest.mark.parametrize("name", ["teapot_cornell", "grid_small", "textured_c2"])
+@pytest.mark.parametrize("name", ["teapot_cornell", "grid_small", "textured_c2", "stress_layout"])
 def test_traversal_schedule_same_results(built, name, monkeypatch):
     """MI355PT_OWNER_LANES=3 lets only 3 lanes of a wave own rays: the other 61 steal subtrees all the time;
     MI355PT_NODE_LANES=64 drains the leaf queue after almost every node step.  Hits and radiance must not
