@@ -109,6 +109,17 @@ class PathTracer:
         capi.check(self.lib, self.lib.mi355pt_render_read_rgb8(self.h, out.ctypes.data), "read_rgb8")
         return out
 
+    def SaveImage(self, path="colorbuffer.png"):
+        """RayTracer::SaveBuffer -> renderImage.SaveImage("colorbuffer.png") (src/raytracer.cpp:461-474): the RGB8
+        frame as an 8-bit PNG (the reference writes it with lodepng; rows top to bottom)."""
+        save_png_rgb8(path, self.GetPixels())
+
+    def Restart(self):
+        """RayTracer::Restart (src/raytracer.cpp:377-382): stop, then start over with an empty accumulator."""
+        self.Pause()
+        self.Join()
+        self.Init(self.width, self.height)
+
     def read_accum(self):
         mean = np.zeros((self.size, 3), dtype=np.float32)
         cnt = np.zeros(self.size, dtype=np.uint32)
@@ -178,3 +189,18 @@ class PathTracer:
             self.close_render()
         except Exception:
             pass
+
+
+def save_png_rgb8(path, img):
+    """Minimal PNG writer: (h, w, 3) uint8, filter 0 on every row, one zlib stream."""
+    import struct
+    import zlib
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    h, w = img.shape[:2]
+    raw = np.concatenate([np.zeros((h, 1), dtype=np.uint8), img.reshape(h, w * 3)], axis=1).tobytes()
+
+    def chunk(typ, body):
+        return struct.pack(">I", len(body)) + typ + body + struct.pack(">I", zlib.crc32(typ + body) & 0xFFFFFFFF)
+    with open(path, "wb") as f:
+        f.write(b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, 2, 0, 0, 0)) +
+                chunk(b"IDAT", zlib.compress(raw, 6)) + chunk(b"IEND", b""))

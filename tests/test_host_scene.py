@@ -121,3 +121,14 @@ def test_c4_grid_is_ten_million_triangles_by_construction():
     assert m.faces.shape[0] == 6 * 240
     m2 = scenes.instanced_grid_mesh(3, 2)
     assert np.array_equal(m.vertices, m2.vertices)                        # deterministic (seed 1234)
+
+
+def test_png_writer_roundtrip(tmp_path):
+    """SaveImage's PNG writer against the PNG decoder used for textures (which flips rows like the reference's loader)."""
+    from pathtracer_amd.pathtracer import save_png_rgb8
+    from pathtracer_amd.scene import load_png_rgb8
+    rng = np.random.default_rng(3)
+    img = rng.integers(0, 256, (13, 17, 3), dtype=np.uint8)
+    p = tmp_path / "colorbuffer.png"
+    save_png_rgb8(str(p), img)
+    assert np.array_equal(load_png_rgb8(str(p)), img[::-1])
