@@ -200,6 +200,8 @@ __global__ void __launch_bounds__(kExtBlock) k_trace(DScene S, DPaths P, Params 
     float bt = kBig, pabs = 0.0f;
     float best_t = kBig; int best_inst = -1, best_mesh = -1; uint32_t best_slot = 0;      // closest: best over the objects so far
     float bound = 0.0f; uint32_t linst = 0;                                                // any: distance bound, the light's object
+    float4* recl = (float4*)(aux + kLdsRec);
+    // the ray of an item, already taken into the root node's space (level 0 of every object's chain)
     auto load_world = [&](uint32_t it, Ray& wr) {                // closest: `it` is a path slot; any: slot * 2 + which
         if (!ANY) {
             wr.p = xyz(P.ray[2 * (size_t)it]); wr.d = xyz(P.ray[2 * (size_t)it + 1]);
@@ -207,6 +209,7 @@ __global__ void __launch_bounds__(kExtBlock) k_trace(DScene S, DPaths P, Params 
             const float4* sh = P.sh + (size_t)(it >> 1) * kShVec;
             wr.p = xyz(sh[SHV_O]); wr.d = xyz(sh[(it & 1u) ? SHV_W2 : SHV_W1]);
         }
+        if (S.num_recs > 0) wr = rec_ray(S, recl, 1u, 0u, wr);   // record 0 is cached in LDS; its level 0 is the root node
     };
     uint32_t qh = 0, nq = 0;                                     // leaf queue (ring): head, count -- wave-uniform
     const uint32_t nwaves = gridDim.x;
@@ -218,7 +221,6 @@ __global__ void __launch_bounds__(kExtBlock) k_trace(DScene S, DPaths P, Params 
     const bool trickle = n < 64u * nwaves;
     if (trickle) { chunk = (n + nwaves - 1u) / nwaves; chunk = chunk < 4u ? 4u : chunk; }
     if (blockIdx.x * chunk >= n) return;                         // nothing left for this wave even on the first deal
-    float4* recl = (float4*)(aux + kLdsRec);
     const uint32_t ncache = (uint32_t)S.num_recs < kRecCache ? (uint32_t)S.num_recs : kRecCache;
     for (uint32_t i = lane; i < ncache * kRecStride; i += 64u) recl[i] = S.recs[i];
     __syncthreads();
@@ -255,19 +257,16 @@ __global__ void __launch_bounds__(kExtBlock) k_trace(DScene S, DPaths P, Params 
                         if (idx < pool_end) {
                             slot = q ? q[idx] : idx;
                             rec = 0; state = LS_SETUP;
-                            if (!ANY) {
-                                wr.p = xyz(P.ray[2 * (size_t)slot]); wr.d = xyz(P.ray[2 * (size_t)slot + 1]);
-                                best_t = kBig; best_inst = -1; best_mesh = -1; best_slot = 0;
-                            } else {
+                            load_world(slot, wr);
+                            if (!ANY) { best_t = kBig; best_inst = -1; best_mesh = -1; best_slot = 0; }
+                            else {
                                 // (1) the light's own object, both sides: a miss or its back side blocks (raytracer.cpp:67-97,138-145)
                                 const float4* sh = P.sh + (size_t)(slot >> 1) * kShVec;
-                                const float4 so = sh[SHV_O], sw = sh[(slot & 1u) ? SHV_W2 : SHV_W1];
-                                wr.p = xyz(so); wr.d = xyz(sw);
-                                const float tmax = (slot & 1u) ? kBig : so.w;
-                                const DLight& L = S.lights[__float_as_int(sw.w)];
+                                const float tmax = (slot & 1u) ? kBig : sh[SHV_O].w;
+                                const DLight& L = S.lights[__float_as_int(sh[SHV_W1].w)];
                                 linst = (uint32_t)L.inst;
                                 const float4* R = (uint32_t)L.rec < ncache ? (const float4*)(recl + L.rec * kRecStride) : S.recs + (size_t)L.rec * kRecStride;
-                                const Ray lr = rec_ray(S, R, __float_as_uint(R[0].y), linst, wr);
+                                const Ray lr = rec_ray(S, R, __float_as_uint(R[0].y), linst, wr, 1u);
                                 float lz; bool front; F3 Pp;
                                 if (!plane_hit(lr.p, lr.d, SIDE_BOTH, lz, front, Pp) || !front) { P.vis[slot] = 1; state = LS_IDLE; }
                                 else bound = tmax < lz ? tmax : lz;              // (2) blocks iff z < tmax && z < lightZ
@@ -295,7 +294,7 @@ __global__ void __launch_bounds__(kExtBlock) k_trace(DScene S, DPaths P, Params 
                         const uint32_t kind = __float_as_uint(h0.x), clen = __float_as_uint(h0.y), nexti = __float_as_uint(h0.z), rflags = __float_as_uint(h0.w);
                         const uint32_t rii = __float_as_uint(h1.x);
                         if (ANY && rii == linst) { rec = nexti; continue; }           // the light's own object is not an occluder
-                        const Ray lr = rec_ray(S, R, clen, rii, wr);
+                        const Ray lr = rec_ray(S, R, clen, rii, wr, 1u);
                         if (kind != MI355PT_OBJ_MODEL) {                  // analytic objects: Plane, Sphere (objects.cpp:474-790)
                             float t; bool front; F3 Pp;
                             const int side = ANY ? SIDE_FRONT : SIDE_BOTH;

@@ -169,9 +169,11 @@ PT_DEV Ray to_inst(const DScene& S, const DInst& in, Ray r) {
     return r;
 }
 
-// Ray into the space of a walk record's object (pt_scene.h): ToNodeCoords level by level, root first.
-PT_DEV Ray rec_ray(const DScene& S, const float4* R, uint32_t chain_len, uint32_t inst, Ray r) {
-    for (uint32_t l = 0; l < chain_len; l++) {
+// Ray into the space of a walk record's object (pt_scene.h): ToNodeCoords level by level, root first.  Every chain
+// starts at the scene's root node, so callers that walk several records for one ray apply level 0 once
+// (first_level = 1 with the ray already in the root's space): same arithmetic, done once instead of per object.
+PT_DEV Ray rec_ray(const DScene& S, const float4* R, uint32_t chain_len, uint32_t inst, Ray r, uint32_t first_level = 0) {
+    for (uint32_t l = first_level; l < chain_len; l++) {
         if (l < (uint32_t)kRecLevels) {
             const float4 a = R[7 + 3 * l], b = R[8 + 3 * l], c = R[9 + 3 * l];
             const float itm[9] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x};
