@@ -50,9 +50,8 @@ struct DPaths {
     uint32_t *queue[2];   // path-slot indices, ping-pong
     uint32_t *squeue;     // slots with shadow work this bounce
     uint32_t *counts;     // [b] = #paths entering bounce b (b >= 1)
-    uint32_t *scounts;    // [b] = #paths with shadow work at bounce b
+    unsigned long long *svcounts;   // [b] = (#visibility items << 32) | #paths with shadow work at bounce b: one atomic reserves both
     uint32_t *vqueue;     // visibility items of this bounce: slot * 2 + which (0 = light sample, 1 = MIS BRDF sample)
-    uint32_t *vcounts;    // [b] = #visibility items at bounce b
     uint32_t *vwork;      // [b] = next vqueue index to hand out in k_trace<ANY>
     uint8_t  *vis;        // [2 x cap] 1 = blocked, per visibility item
     uint32_t *work;       // [b] = next queue index to hand out in k_trace<closest> of bounce b (persistent refill)
@@ -179,7 +178,7 @@ __device__ __forceinline__ float key_dist(unsigned long long k) { return (k & 1u
 // front-face hit nearer than min(tmax, distance to the light); the walk of a blocked ray is abandoned at once.
 template <bool ANY, bool COUNT>
 __global__ void __launch_bounds__(kExtBlock) k_trace(DScene S, DPaths P, Params prm, uint32_t bounce, uint32_t n0) {
-    const uint32_t n = ANY ? P.vcounts[bounce] : (bounce == 0 ? n0 : P.counts[bounce]);
+    const uint32_t n = ANY ? (uint32_t)(P.svcounts[bounce] >> 32) : (bounce == 0 ? n0 : P.counts[bounce]);
     const uint32_t* q = ANY ? P.vqueue : (bounce == 0 ? nullptr : P.queue[bounce & 1]);
     uint32_t* work = ANY ? &P.vwork[bounce] : &P.work[bounce];
     extern __shared__ uint32_t sm[];
@@ -544,6 +543,31 @@ __global__ void __launch_bounds__(kShadeBlock) __attribute__((amdgpu_waves_per_e
     const uint32_t* q = bounce == 0 ? nullptr : P.queue[bounce & 1];
     uint32_t* qnext = P.queue[(bounce + 1) & 1];
     __shared__ uint32_t hits[128];
+    // Outputs (next-bounce queue, shadow-work slots, visibility items) are collected in LDS over several passes and
+    // written with ONE reservation per queue pair: every wave of the chip appending to the same three device-wide
+    // counters once per pass cost ~1 ms of a 3 ms launch (same-address device-scope atomics serialise).
+    constexpr uint32_t kOut = 256;
+    __shared__ uint32_t ob_alive[kOut], ob_sq[kOut], ob_vq[2 * kOut];
+    uint32_t na = 0, ns = 0, nv = 0;                              // wave-uniform fill counts
+    auto flush = [&]() {
+        __syncthreads();
+        if (na) {
+            uint32_t base = 0;
+            if (threadIdx.x == 0) base = atomicAdd(&P.counts[bounce + 1], na);
+            base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+            for (uint32_t k = threadIdx.x; k < na; k += 64u) qnext[base + k] = ob_alive[k];
+        }
+        if (ns | nv) {
+            unsigned long long old = 0;
+            if (threadIdx.x == 0) old = atomicAdd(&P.svcounts[bounce], ((unsigned long long)nv << 32) | (unsigned long long)ns);
+            const uint32_t sbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(old & 0xFFFFFFFFull));
+            const uint32_t vbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(old >> 32));
+            for (uint32_t k = threadIdx.x; k < ns; k += 64u) P.squeue[sbase + k] = ob_sq[k];
+            for (uint32_t k = threadIdx.x; k < nv; k += 64u) P.vqueue[vbase + k] = ob_vq[k];
+        }
+        na = ns = nv = 0;
+        __syncthreads();
+    };
     const uint32_t lane = threadIdx.x;
     const unsigned long long lt = (1ull << lane) - 1ull;
     uint32_t nh = 0;                                              // hits waiting in LDS (wave-uniform)
@@ -567,7 +591,7 @@ __global__ void __launch_bounds__(kShadeBlock) __attribute__((amdgpu_waves_per_e
             if (hit) hits[nh + (uint32_t)__popcll(hm & lt)] = gslot;
             nh += (uint32_t)__popcll(hm);
         }
-        if (nh == 0) break;
+        if (nh == 0) { flush(); break; }
         __syncthreads();
         const uint32_t take = nh < 64u ? nh : 64u;
         const bool act = lane < take;
@@ -661,10 +685,16 @@ __global__ void __launch_bounds__(kShadeBlock) __attribute__((amdgpu_waves_per_e
                 }
             }
         }
-        wave_enqueue(alive, slot, qnext, &P.counts[bounce + 1]);
-        wave_enqueue(shadow, slot, P.squeue, &P.scounts[bounce]);
-        wave_enqueue(shadow && (vflags & 1u), slot * 2u, P.vqueue, &P.vcounts[bounce]);
-        wave_enqueue(shadow && (vflags & 2u), slot * 2u + 1u, P.vqueue, &P.vcounts[bounce]);
+        {
+            const unsigned long long ma = __ballot(alive), ms = __ballot(shadow);
+            const unsigned long long m1 = __ballot(shadow && (vflags & 1u)), m2 = __ballot(shadow && (vflags & 2u));
+            if (alive) ob_alive[na + (uint32_t)__popcll(ma & lt)] = slot;
+            if (shadow) ob_sq[ns + (uint32_t)__popcll(ms & lt)] = slot;
+            if (shadow && (vflags & 1u)) ob_vq[nv + (uint32_t)__popcll(m1 & lt)] = slot * 2u;
+            if (shadow && (vflags & 2u)) ob_vq[nv + (uint32_t)__popcll(m1) + (uint32_t)__popcll(m2 & lt)] = slot * 2u + 1u;
+            na += (uint32_t)__popcll(ma); ns += (uint32_t)__popcll(ms); nv += (uint32_t)__popcll(m1) + (uint32_t)__popcll(m2);
+            if (na > kOut - 64u || ns > kOut - 64u || nv > 2u * kOut - 128u) flush();
+        }
     }
 }
 
@@ -673,7 +703,7 @@ __global__ void __launch_bounds__(kShadeBlock) __attribute__((amdgpu_waves_per_e
 // `color += throughput * SampleLights(...)` of render.h:148.  The visibility traces themselves were
 // done by k_trace<ANY>; this kernel combines their results.
 __global__ void __launch_bounds__(kBlock) k_connect(DScene S, DPaths P, uint32_t bounce) {
-    const uint32_t n = P.scounts[bounce];
+    const uint32_t n = (uint32_t)(P.svcounts[bounce] & 0xFFFFFFFFull);
     unsigned long long rays = 0;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const uint32_t slot = P.squeue[i];
@@ -1141,8 +1171,8 @@ int mi355pt_render_create(mi355pt_scene* scene, const mi355pt_render_params* par
     HIP_TRY(dalloc((void**)&P.hit, cap * 16)); HIP_TRY(dalloc((void**)&P.sh, cap * 16 * kShVec));
     HIP_TRY(dalloc((void**)&P.queue[0], cap * 4)); HIP_TRY(dalloc((void**)&P.queue[1], cap * 4)); HIP_TRY(dalloc((void**)&P.squeue, cap * 4));
     const size_t nb = params->max_bounces + 2;
-    HIP_TRY(dalloc((void**)&P.counts, nb * 4)); HIP_TRY(dalloc((void**)&P.scounts, nb * 4)); HIP_TRY(dalloc((void**)&P.work, nb * 4));
-    HIP_TRY(dalloc((void**)&P.vqueue, cap * 8)); HIP_TRY(dalloc((void**)&P.vcounts, nb * 4)); HIP_TRY(dalloc((void**)&P.vwork, nb * 4));
+    HIP_TRY(dalloc((void**)&P.counts, nb * 4)); HIP_TRY(dalloc((void**)&P.svcounts, nb * 8)); HIP_TRY(dalloc((void**)&P.work, nb * 4));
+    HIP_TRY(dalloc((void**)&P.vqueue, cap * 8)); HIP_TRY(dalloc((void**)&P.vwork, nb * 4));
     HIP_TRY(dalloc((void**)&P.vis, cap * 2));
     HIP_TRY(dalloc((void**)&P.stat, 16 * sizeof(unsigned long long)));
     HIP_TRY(hipMemsetAsync(P.stat, 0, 16 * sizeof(unsigned long long), r->stream));
@@ -1227,9 +1257,8 @@ int run_paths(mi355pt_render* r, uint32_t n, uint32_t jitter = 1, uint32_t only_
     Params prm{p.seed, p.width, p.height, p.max_bounces, p.rr_start, r->stack_entries, r->node_lanes, r->owner_lanes};
     const size_t nb = p.max_bounces + 2;
     HIP_TRY(hipMemsetAsync(P.counts, 0, nb * 4, r->stream));
-    HIP_TRY(hipMemsetAsync(P.scounts, 0, nb * 4, r->stream));
+    HIP_TRY(hipMemsetAsync(P.svcounts, 0, nb * 8, r->stream));
     HIP_TRY(hipMemsetAsync(P.work, 0, nb * 4, r->stream));
-    HIP_TRY(hipMemsetAsync(P.vcounts, 0, nb * 4, r->stream));
     HIP_TRY(hipMemsetAsync(P.vwork, 0, nb * 4, r->stream));
     const int g = grid_for(r, n);
     const int ge = (int)std::max<size_t>(1, std::min<size_t>(((size_t)n + 63) / 64, (size_t)r->extend_grid));     // persistent: resident waves only
