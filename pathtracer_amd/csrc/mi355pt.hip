@@ -55,6 +55,7 @@ struct DPaths {
     uint32_t *vwork;      // [b] = next vqueue index to hand out in k_trace<ANY>
     uint8_t  *vis;        // [2 x cap] 1 = blocked, per visibility item
     uint32_t *work;       // [b] = next queue index to hand out in k_trace<closest> of bounce b (persistent refill)
+    uint32_t *spill;      // per resident wave: kStackSize x 64 dwords, the part of a lane's stack below its LDS window
     unsigned long long *stat;   // [0] closest rays [1] shadow rays [2] samples [3,4] extend node visits / tri tests [5,6] visibility ditto [7] guard
 };
 struct Params { uint32_t seed, width, height, max_bounces, rr_start, stack_entries, node_lanes, owner_lanes; };
@@ -192,9 +193,16 @@ __global__ void __launch_bounds__(kExtBlock) k_trace(DScene S, DPaths P, Params 
     uint32_t* nwork = aux + kLdsWork;                            // [64] lanes still walking for this owner
     uint32_t* xfer = aux + kLdsXfer;                             // [128] steal hand-over
     uint8_t* tril = (uint8_t*)(aux + kLdsTri);                   // [256] expanded triangle list of one drain round
-#define PT_STK(i) stk[(i) * 64 + lane]
+    // A lane's traversal stack is logical entries [sb, sp); the top `stack_entries` (a power of two) of them live in an
+    // LDS ring, entries below `lo` in the wave's spill area in global memory.  Depth-first, near-child-first walks keep a
+    // stack of about one entry per level with both children hit: the window is rarely left, and a 16-entry window instead
+    // of a full-depth stack is what lets 16 instead of 12 waves share a CU's LDS.
+    const uint32_t rmask = prm.stack_entries - 1u;
+    uint32_t* spill = P.spill + (size_t)blockIdx.x * kStackSize * 64;
+#define PT_STK(i) stk[((i) & rmask) * 64 + lane]
+#define PT_SPILL(i) spill[(i) * 64 + lane]
     WorkCounters wc; wc.nodes = 0; wc.tris = 0;
-    uint32_t state = LS_IDLE, slot = 0, rec = 0, sp = 0, sb = 0, owner = lane;
+    uint32_t state = LS_IDLE, slot = 0, rec = 0, sp = 0, sb = 0, lo = 0, owner = lane;
     F3 o = f3(0, 0, 0), inv = f3(0, 0, 0);
     float bt = kBig, pabs = 0.0f;
     float best_t = kBig; int best_inst = -1, best_mesh = -1; uint32_t best_slot = 0;      // closest: best over the objects so far
@@ -320,7 +328,7 @@ __global__ void __launch_bounds__(kExtBlock) k_trace(DScene S, DPaths P, Params 
                         rayl[2 * lane] = make_float4(lr.p.x, lr.p.y, lr.p.z, bound);
                         rayl[2 * lane + 1] = make_float4(lr.d.x, lr.d.y, lr.d.z, 0.0f);
                         keyl[lane] = ANY ? 0ull : hit_key(best_t, 0u) & ~1ull;       // any: 1 = blocked
-                        owner = lane; sb = 0;
+                        owner = lane; sb = 0; lo = 0;
                         if (root_cnt >= kChain) {
                             o = lr.p; inv = linv; pabs = prune_abs(lr.p); bt = ANY ? bound : best_t;
                             PT_STK(0) = root_ref; sp = 1; nwork[lane] = 1; state = LS_TRAV;
@@ -359,7 +367,9 @@ __global__ void __launch_bounds__(kExtBlock) k_trace(DScene S, DPaths P, Params 
                 uint32_t leafL = 0, leafR = 0;
                 if (want) {
                     sp--;
-                    const uint32_t e = PT_STK(sp);
+                    uint32_t e;
+                    if (sp >= lo) e = PT_STK(sp);
+                    else { e = PT_SPILL(sp); lo = sp; }                  // the window is empty: the next entry comes back from the spill area
                     const float4* np = S.bvh_nodes + 4 * (size_t)e;
                     const float4 w0 = np[0], w1 = np[1], w2 = np[2], w3 = np[3];
                     if (COUNT) wc.nodes++;
@@ -402,9 +412,11 @@ __global__ void __launch_bounds__(kExtBlock) k_trace(DScene S, DPaths P, Params 
                     const bool rnear = pushL & pushR & (tr < tl);
                     const uint32_t e0 = pushL ? (rnear ? lref : (pushR ? rref : lref)) : rref;    // deeper entry (far child, or the only one)
                     const uint32_t e1 = rnear ? rref : lref;                                      // top entry when both are pushed
+                    const uint32_t npush = (pushL ? 1u : 0u) + (pushR ? 1u : 0u);
+                    while (sp + npush > lo + prm.stack_entries) { PT_SPILL(lo) = PT_STK(lo); lo++; }      // make room in the window (at most twice)
                     if (pushL | pushR) PT_STK(sp) = e0;
                     if (pushL & pushR) PT_STK(sp + 1) = e1;
-                    sp += (pushL ? 1u : 0u) + (pushR ? 1u : 0u);
+                    sp += npush;
                 }
                 const unsigned long long mL = __ballot(leafL != 0u), mR = __ballot(leafR != 0u);
                 if (mL | mR) {
@@ -469,7 +481,7 @@ __global__ void __launch_bounds__(kExtBlock) k_trace(DScene S, DPaths P, Params 
         if (state == LS_TRAV || state == LS_THIEF) {
             const unsigned long long k = keyl[owner];
             if (!ANY) bt = __uint_as_float((uint32_t)(k >> 32));
-            else if (k) { sp = sb; atomicSub(&nwork[owner], 1u); state = state == LS_TRAV ? LS_WAIT : (exhausted ? LS_DONE : LS_IDLE); }   // blocked: abandon the walk
+            else if (k) { sp = sb; lo = sb; atomicSub(&nwork[owner], 1u); state = state == LS_TRAV ? LS_WAIT : (exhausted ? LS_DONE : LS_IDLE); }   // blocked: abandon the walk
         }
         __syncthreads();
         if (state == LS_WAIT && nwork[lane] == 0u) {                    // every lane that walked for this ray is done, the queue is empty
@@ -501,7 +513,7 @@ __global__ void __launch_bounds__(kExtBlock) k_trace(DScene S, DPaths P, Params 
             if (k) {
                 if (can_give) {
                     const uint32_t r = (uint32_t)__popcll(donors & lt);
-                    if (r < k) { xfer[r] = PT_STK(sb); xfer[64 + r] = owner; sb++; atomicAdd(&nwork[owner], 1u); }
+                    if (r < k) { xfer[r] = sb >= lo ? PT_STK(sb) : PT_SPILL(sb); xfer[64 + r] = owner; sb++; lo = lo < sb ? sb : lo; atomicAdd(&nwork[owner], 1u); }
                 }
                 __syncthreads();
                 if (free_lane) {
@@ -511,7 +523,7 @@ __global__ void __launch_bounds__(kExtBlock) k_trace(DScene S, DPaths P, Params 
                         const float4 ro = rayl[2 * owner], rd = rayl[2 * owner + 1];
                         o = f3(ro.x, ro.y, ro.z); inv = f3(1.0f, 1.0f, 1.0f) / f3(rd.x, rd.y, rd.z); pabs = prune_abs(o);
                         bt = ANY ? ro.w : __uint_as_float((uint32_t)(keyl[owner] >> 32));
-                        PT_STK(0) = xfer[r]; sp = 1; sb = 0; state = LS_THIEF;
+                        PT_STK(0) = xfer[r]; sp = 1; sb = 0; lo = 0; state = LS_THIEF;
                     }
                 }
                 __syncthreads();
@@ -520,6 +532,7 @@ __global__ void __launch_bounds__(kExtBlock) k_trace(DScene S, DPaths P, Params 
         PT_PHASE(ck_rest);
     }
 #undef PT_STK
+#undef PT_SPILL
 #undef PT_PHASE
     if (COUNT) { wave_add64(wc.nodes, &P.stat[ANY ? 5 : 3]); wave_add64(wc.tris, &P.stat[ANY ? 6 : 4]);
         if (!ANY && lane == 0) { atomicAdd(&P.stat[8], ck_setup); atomicAdd(&P.stat[9], ck_node); atomicAdd(&P.stat[10], ck_drain); atomicAdd(&P.stat[11], ck_rest);
@@ -1198,13 +1211,16 @@ int mi355pt_render_create(mi355pt_scene* scene, const mi355pt_render_params* par
     r->grid = prop.multiProcessorCount * 8;
     {   // persistent extend kernel: one wave per workgroup, LDS = stack of (tree depth + 4) dwords per lane + the wave's
         // queues; the grid is the number of waves that are resident at once
-        const int entries = std::min(kStackSize, std::max(8, scene->max_depth + 3));
+        const int need = std::max(8, scene->max_depth + 3);            // deepest stack a walk can build (host-checked <= kStackSize)
+        int entries = need <= 8 ? 8 : 16;                              // LDS window (power of two); deeper entries spill to P.spill
+        if (const char* e = getenv("MI355PT_STACK_WINDOW")) entries = atoi(e) <= 4 ? 4 : (atoi(e) <= 8 ? 8 : 16);     // test knob: a small window spills all the time
         r->stack_entries = (uint32_t)entries;
         r->extend_lds = extend_lds_bytes((uint32_t)entries);
         int waves = 0;
         HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&waves, k_trace<false, false>, kExtBlock, r->extend_lds));
         if (const char* e = getenv("MI355PT_EXTEND_WAVES_PER_CU")) waves = std::min(waves, std::max(1, atoi(e)));
         r->extend_grid = prop.multiProcessorCount * std::max(1, waves);
+        HIP_TRY(dalloc((void**)&P.spill, (size_t)r->extend_grid * kStackSize * 64 * 4));
     }
     // test knobs: results must not depend on either (tests/test_gpu_parity.py::test_traversal_schedule_*)
     if (const char* e = getenv("MI355PT_NODE_LANES")) r->node_lanes = (uint32_t)std::min(64, std::max(1, atoi(e)));

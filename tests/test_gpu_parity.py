@@ -157,11 +157,13 @@ def test_errors_are_loud(built):
 @pytest.mark.parametrize("name", ["teapot_cornell", "grid_small", "textured_c2", "stress_layout"])
 def test_traversal_schedule_same_results(built, name, monkeypatch):
     """MI355PT_OWNER_LANES=3 lets only 3 lanes of a wave own rays: the other 61 steal subtrees all the time;
-    MI355PT_NODE_LANES=64 drains the leaf queue after almost every node step.  Hits and radiance must not
-    depend on who walks which subtree, or when its triangles are tested."""
+    MI355PT_NODE_LANES=64 drains the leaf queue after almost every node step; MI355PT_STACK_WINDOW=4 keeps only
+    four stack entries in LDS.  Hits and radiance must not depend on who walks which subtree, when its triangles
+    are tested, or where a stack entry was kept."""
     s, orc, pt, w, h = built(name)
     monkeypatch.setenv("MI355PT_OWNER_LANES", "3")
     monkeypatch.setenv("MI355PT_NODE_LANES", "64")
+    monkeypatch.setenv("MI355PT_STACK_WINDOW", "4")          # 4-entry LDS stack window: deeper entries go through the spill area
     p2 = PathTracer(pt.dscene)
     p2.Init(w, h)
     node, mesh, face, t = p2.trace_primary()
@@ -199,6 +201,7 @@ def test_full_size_10m_triangle_scene(monkeypatch):
     a, _ = pt.sample_radiance(pixel, sample)
     monkeypatch.setenv("MI355PT_OWNER_LANES", "5")
     monkeypatch.setenv("MI355PT_NODE_LANES", "8")
+    monkeypatch.setenv("MI355PT_STACK_WINDOW", "4")
     p2 = PathTracer(pt.dscene)
     p2.Init(w, h)
     b, _ = p2.sample_radiance(pixel, sample)
