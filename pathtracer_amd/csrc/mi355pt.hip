@@ -288,6 +288,52 @@ __global__ void __launch_bounds__(kExtBlock) k_trace(DScene S, DPaths P, Params 
                 // ---- TraceNode's / LightVisTest's walk over the objects (earlier object wins ties, raytracer.cpp:208,238),
                 // record by record, until a mesh has to be traversed or the ray is finished
                 uint32_t root_leaf = 0;                               // leaf item to enqueue when a mesh's root is a leaf
+                // processes record `rec`; returns true when the lane has left the object walk (traversal started, or ray finished)
+                auto walk_rec = [&](auto R) -> bool {
+                    const float4 h0 = R[0], h1 = R[1];
+                    const uint32_t kind = __float_as_uint(h0.x), clen = __float_as_uint(h0.y), nexti = __float_as_uint(h0.z), rflags = __float_as_uint(h0.w);
+                    const uint32_t rii = __float_as_uint(h1.x);
+                    if (ANY && rii == linst) { rec = nexti; return false; }           // the light's own object is not an occluder
+                    const Ray lr = rec_ray(S, R, clen, rii, wr, 1u);
+                    if (kind != MI355PT_OBJ_MODEL) {                  // analytic objects: Plane, Sphere (objects.cpp:474-790)
+                        float t; bool front; F3 Pp;
+                        const int side = ANY ? SIDE_FRONT : SIDE_BOTH;
+                        const bool hit = kind == MI355PT_OBJ_PLANE ? plane_hit(lr.p, lr.d, side, t, front, Pp) : sphere_hit(lr.p, lr.d, side, t, front, Pp);
+                        if (ANY) {
+                            if (hit && t < bound) { P.vis[slot] = 1; state = LS_IDLE; return true; }
+                        } else if (hit && t < best_t) { best_t = t; best_inst = (int)rii; best_mesh = -1; best_slot = 0; }
+                        rec = nexti;
+                        return false;
+                    }
+                    const F3 linv = f3(1.0f, 1.0f, 1.0f) / lr.d;
+                    const float4 b0 = R[2], b1 = R[3], b2 = R[4], b3 = R[5], b4 = R[6];
+                    const float model_box[6] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y}, mesh_box[6] = {b1.z, b1.w, b2.x, b2.y, b2.z, b2.w};
+                    const float root_box[6] = {b3.x, b3.y, b3.z, b3.w, b4.x, b4.y};
+                    const uint32_t root_ref = __float_as_uint(h1.z), root_cnt = __float_as_uint(h1.w);
+                    float tn;
+                    const bool in_model = slab_straight(model_box, lr.p, linv, tn);          // Model::IntersectRay, model.cpp:212
+                    const bool in_mesh = slab_straight(mesh_box, lr.p, linv, tn);            // model.cpp:223-245
+                    const bool in_root = slab_straight(root_box, lr.p, linv, tn);
+                    if ((rflags & 1u) && !in_model) { rec = nexti; return false; }
+                    bool go = in_mesh;
+                    if (go && root_cnt == kInternal) { if (COUNT) wc.nodes++; go = in_root; }
+                    if (go && root_cnt == 0u) go = false;
+                    if (!go) { rec++; return false; }
+                    // the mesh starts from the best so far with slot key 0: an equal-t candidate of a later
+                    // mesh / object loses (model.cpp:237), only a strictly closer one replaces it
+                    rayl[2 * lane] = make_float4(lr.p.x, lr.p.y, lr.p.z, bound);
+                    rayl[2 * lane + 1] = make_float4(lr.d.x, lr.d.y, lr.d.z, 0.0f);
+                    keyl[lane] = ANY ? 0ull : hit_key(best_t, 0u) & ~1ull;       // any: 1 = blocked
+                    owner = lane; sb = 0; lo = 0;
+                    if (root_cnt >= kChain) {
+                        o = lr.p; inv = linv; pabs = prune_abs(lr.p); bt = ANY ? bound : best_t;
+                        PT_STK(0) = root_ref; sp = 1; nwork[lane] = 1; state = LS_TRAV;
+                    } else {
+                        root_leaf = kLeafFlag | ((root_cnt - 1u) << 27) | root_ref;
+                        sp = 0; nwork[lane] = 0; state = LS_WAIT;
+                    }
+                    return true;
+                };
                 if (state == LS_SETUP) {
                     for (;;) {
                         if (rec >= (uint32_t)S.num_recs) {
@@ -296,47 +342,9 @@ __global__ void __launch_bounds__(kExtBlock) k_trace(DScene S, DPaths P, Params 
                             state = LS_IDLE;
                             break;
                         }
-                        const float4* R = rec < ncache ? (const float4*)(recl + rec * kRecStride) : S.recs + (size_t)rec * kRecStride;
-                        const float4 h0 = R[0], h1 = R[1];
-                        const uint32_t kind = __float_as_uint(h0.x), clen = __float_as_uint(h0.y), nexti = __float_as_uint(h0.z), rflags = __float_as_uint(h0.w);
-                        const uint32_t rii = __float_as_uint(h1.x);
-                        if (ANY && rii == linst) { rec = nexti; continue; }           // the light's own object is not an occluder
-                        const Ray lr = rec_ray(S, R, clen, rii, wr, 1u);
-                        if (kind != MI355PT_OBJ_MODEL) {                  // analytic objects: Plane, Sphere (objects.cpp:474-790)
-                            float t; bool front; F3 Pp;
-                            const int side = ANY ? SIDE_FRONT : SIDE_BOTH;
-                            const bool hit = kind == MI355PT_OBJ_PLANE ? plane_hit(lr.p, lr.d, side, t, front, Pp) : sphere_hit(lr.p, lr.d, side, t, front, Pp);
-                            if (ANY) {
-                                if (hit && t < bound) { P.vis[slot] = 1; state = LS_IDLE; break; }
-                            } else if (hit && t < best_t) { best_t = t; best_inst = (int)rii; best_mesh = -1; best_slot = 0; }
-                            rec = nexti;
-                            continue;
-                        }
-                        const F3 linv = f3(1.0f, 1.0f, 1.0f) / lr.d;
-                        const float4 b0 = R[2], b1 = R[3], b2 = R[4], b3 = R[5], b4 = R[6];
-                        const float model_box[6] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y}, mesh_box[6] = {b1.z, b1.w, b2.x, b2.y, b2.z, b2.w};
-                        const float root_box[6] = {b3.x, b3.y, b3.z, b3.w, b4.x, b4.y};
-                        const uint32_t root_ref = __float_as_uint(h1.z), root_cnt = __float_as_uint(h1.w);
-                        float tn;
-                        if ((rflags & 1u) && !slab(model_box, lr.p, linv, tn)) { rec = nexti; continue; }      // Model::IntersectRay, model.cpp:212
-                        bool go = slab(mesh_box, lr.p, linv, tn);                                              // model.cpp:223-245
-                        if (go && root_cnt == kInternal) { if (COUNT) wc.nodes++; go = slab(root_box, lr.p, linv, tn); }
-                        if (go && root_cnt == 0u) go = false;
-                        if (!go) { rec++; continue; }
-                        // the mesh starts from the best so far with slot key 0: an equal-t candidate of a later
-                        // mesh / object loses (model.cpp:237), only a strictly closer one replaces it
-                        rayl[2 * lane] = make_float4(lr.p.x, lr.p.y, lr.p.z, bound);
-                        rayl[2 * lane + 1] = make_float4(lr.d.x, lr.d.y, lr.d.z, 0.0f);
-                        keyl[lane] = ANY ? 0ull : hit_key(best_t, 0u) & ~1ull;       // any: 1 = blocked
-                        owner = lane; sb = 0; lo = 0;
-                        if (root_cnt >= kChain) {
-                            o = lr.p; inv = linv; pabs = prune_abs(lr.p); bt = ANY ? bound : best_t;
-                            PT_STK(0) = root_ref; sp = 1; nwork[lane] = 1; state = LS_TRAV;
-                        } else {
-                            root_leaf = kLeafFlag | ((root_cnt - 1u) << 27) | root_ref;
-                            sp = 0; nwork[lane] = 0; state = LS_WAIT;
-                        }
-                        break;
+                        // one record; the cached ones are read with LDS instructions, the others from memory
+                        const bool stop = rec < ncache ? walk_rec((const float4*)(recl + rec * kRecStride)) : walk_rec(S.recs + (size_t)rec * kRecStride);
+                        if (stop) break;
                     }
                 }
                 const unsigned long long rl = __ballot(root_leaf != 0u);

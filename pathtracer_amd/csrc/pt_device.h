@@ -206,6 +206,25 @@ PT_DEV bool slab(const float* b, F3 p, F3 inv, float& tnear) {
     return true;
 }
 
+// The same test without early exits: every operand is used unconditionally, so the compiler keeps the box loads together
+// at the top instead of sinking them into the exits (a dependent round trip each).  Same comparisons, same results.
+PT_DEV bool slab_straight(const float* b, F3 p, F3 inv, float& tnear) {
+    const bool s0 = inv.x < 0, s1 = inv.y < 0, s2 = inv.z < 0;
+    float tmin = ((s0 ? b[3] : b[0]) - p.x) * inv.x;
+    float tmax = ((s0 ? b[0] : b[3]) - p.x) * inv.x;
+    const float tymin = ((s1 ? b[4] : b[1]) - p.y) * inv.y;
+    const float tymax = ((s1 ? b[1] : b[4]) - p.y) * inv.y;
+    bool ok = !((tmin > tymax) || (tymin > tmax));
+    if (tymin > tmin) tmin = tymin;
+    if (tymax < tmax) tmax = tymax;
+    const float tzmin = ((s2 ? b[5] : b[2]) - p.z) * inv.z;
+    const float tzmax = ((s2 ? b[2] : b[5]) - p.z) * inv.z;
+    ok = ok && !((tmin > tzmax) || (tzmin > tmax));
+    if (tzmin > tmin) tmin = tzmin;
+    tnear = tmin;
+    return ok;
+}
+
 // Pruning guard.  The reference has no distance culling at all (bvh.h:88-129 ignores t); skipping a
 // subtree whose slab entry distance lies beyond the best hit is exact in real arithmetic, but the
 // triangle's t (plane equation, cancellation ~ eps * |o| / cos) and the slab's entry distance round
