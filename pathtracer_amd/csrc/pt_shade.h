@@ -101,18 +101,28 @@ PT_DEV void surf_sphere(const Ray& r, bool hasDiff, const Ray& rr, const Ray& tr
     } else { h.du0 = f3(0, 0, 0); h.du1 = f3(0, 0, 0); }
 }
 // FromNodeCoords up the chain (node.h:195-201), as TraceNode applies it level by level
-PT_DEV void surf_to_world(const DScene& S, const DInst& in, Surf& h) {
+// Tangent / Bitangent are read by normal mapping only (disneyMaterial.h:113-121): with_tb = false leaves them alone.
+PT_DEV void surf_to_world(const DScene& S, const DInst& in, Surf& h, bool with_tb) {
     for (int i = in.chain_len - 1; i >= 0; i--) {
         const DNodeXf& n = S.nodes[in.chain[i]];
         h.p = m3mul(n.tm, h.p) + ld3(n.pos);
         h.N = normalized(m3tmul(n.itm, h.N));
-        h.T = normalized(m3tmul(n.itm, h.T));
-        h.B = normalized(m3tmul(n.itm, h.B));
+        if (with_tb) {
+            h.T = normalized(m3tmul(n.itm, h.T));
+            h.B = normalized(m3tmul(n.itm, h.B));
+        }
     }
 }
 // Full HitInfo of a recorded closest hit.
+// Values nothing reads are not computed: the uv differentials feed the texture filter only, Tangent / Bitangent the
+// normal map only, so a hit on a material without maps skips them (what IS computed is computed as the reference does).
 PT_DEV void surf_from_hit(const DScene& S, const HitRec& hr, const Ray& wr, bool hasDiff, F3 rightDir, F3 topDir, Surf& h) {
     const DInst& in = S.insts[hr.inst];
+    h.node = in.node;
+    h.mtl = S.nodes[in.node].material;
+    const mi355pt_material& mt = S.materials[h.mtl];
+    const bool with_tb = mt.normal_map >= 0;
+    hasDiff = hasDiff && (with_tb || mt.albedo_map >= 0 || mt.roughness_map >= 0 || mt.metalness_map >= 0);
     Ray r = wr, rr, tr;
     rr.p = wr.p; rr.d = rightDir; tr.p = wr.p; tr.d = topDir;
     for (int i = 0; i < in.chain_len; i++) {
@@ -123,9 +133,7 @@ PT_DEV void surf_from_hit(const DScene& S, const HitRec& hr, const Ray& wr, bool
     if (in.kind == MI355PT_OBJ_PLANE) surf_plane(r, hasDiff, rr, tr, h);
     else if (in.kind == MI355PT_OBJ_SPHERE) surf_sphere(r, hasDiff, rr, tr, h);
     else surf_triangle(S, S.meshes[S.models[in.model].first_mesh + hr.mesh], hr.slot, r, hasDiff, rr, tr, h);
-    surf_to_world(S, in, h);
-    h.node = in.node;
-    h.mtl = S.nodes[in.node].material;
+    surf_to_world(S, in, h, with_tb);
 }
 
 // ------------------------------------------------------------------ textures (scene.h:157-309, texture.cpp:102-150)
@@ -482,7 +490,7 @@ PT_DEV bool light_hit_point(const DScene& S, const Ray& wr, const DLight& L, F3&
     if (!plane_hit(lr.p, lr.d, SIDE_BOTH, lz, front, P)) return false;
     Surf h; h.p = P; h.N = front ? f3(0.0f, 0.0f, 1.0f) : -1.0f * f3(0.0f, 0.0f, 1.0f);
     h.T = f3(1.0f, 0.0f, 0.0f); h.B = f3(0.0f, 1.0f, 0.0f);
-    surf_to_world(S, li, h);
+    surf_to_world(S, li, h, false);
     lp = h.p; ln = h.N;
     return front;
 }
