@@ -146,7 +146,7 @@ def main():
         distributed.combine_running_means(mean_t, cnt_t, dist, 0)
         torch.cuda.synchronize()
     pt.reset_stats()
-    pt.set_profiling(events=True, count_work=False)     # HIP events around every launch, on the renderer's stream
+    pt.set_profiling(events=1, count_work=False)        # HIP events around every launch of the dominant kernel, on its stream
     npix = args.width * args.height
     barrier()
     t0 = time.perf_counter()
@@ -180,12 +180,29 @@ def main():
                                 + "; one RCCL reduce at the end"},
             "samples_per_pixel_per_s": samples_total / npix / dt,
             "rays_per_sample": rays_total / max(samples_total, 1.0),
-            "kernel_ms": {"extend": st["extend_ms"], "shade": st["shade_ms"], "connect": st["connect_ms"], "other": st["other_ms"]},
         }
     # ---- roofline of the dominant kernel (k_trace<closest>, the extend stage): algorithmic bytes / measured launch time
     if rank == 0 and not args.no_roofline:
         ext_ms, launches = st["extend_ms"], st["extend_launches"]
         closest = st["closest_rays"]
+        # per-stage times of ONE extra, untimed step with events around every stage (the visibility stage overlaps the
+        # next bounce's closest-hit trace on a second stream, so the stages do not add up to the step)
+        pt.set_profiling(events=2, count_work=False)
+        pt.reset_stats()
+        pt.step(spp_step)
+        pt.sync()
+        ks = pt.stats()
+        out["kernel_ms"] = {"extend": ks["extend_ms"], "shade": ks["shade_ms"], "visibility+connect": ks["connect_ms"], "other": ks["other_ms"], "steps": 1}
+        # the same kernel with the chip to itself: one more untimed step with every kernel back to back on one stream.
+        # In the timed region k_trace<closest>(b + 1) shares the CUs with k_trace<any>(b), so its launches last longer
+        # there although the step is shorter; `frac` is the timed region's, `frac_exclusive` this step's.
+        pt.set_overlap(1 << 30)
+        pt.set_profiling(events=1, count_work=False)
+        pt.reset_stats()
+        pt.step(spp_step)
+        pt.sync()
+        xs = pt.stats()
+        pt.set_overlap(0)
         pt.set_profiling(events=False, count_work=True)      # counting build, untimed
         pt.reset_stats()
         pt.step(spp_step)
@@ -206,6 +223,8 @@ def main():
                            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                            "bytes_per_ray": bytes_per_ray, "n_node_per_ray": n_node, "n_tri_per_ray": n_tri,
                            "launches": int(launches), "avg_launch_ms": ext_ms / max(launches, 1),
+                           "frac_exclusive": (xs["closest_rays"] * bytes_per_ray / (xs["extend_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS) if xs["extend_ms"] > 0 else None,
+                           "avg_launch_ms_exclusive": xs["extend_ms"] / max(xs["extend_launches"], 1),
                            "avg_bytes_per_launch": closest * bytes_per_ray / max(launches, 1),
                            "shadow_n_node_per_ray": cs["shadow_node_visits"] / max(cs["shadow_rays"], 1),
                            "shadow_n_tri_per_ray": cs["shadow_tri_tests"] / max(cs["shadow_rays"], 1)}

@@ -274,10 +274,18 @@ int mi355pt_sample_radiance(mi355pt_render* render, const uint32_t* pixel, const
 int mi355pt_render_stats(mi355pt_render* render, mi355pt_stats* stats);
 int mi355pt_render_reset_stats(mi355pt_render* render);
 
-/* Measurement switches (no reference counterpart): enable_events brackets every kernel launch
- * with HIP events on the renderer's stream (summed into mi355pt_stats.*_ms at the next sync);
+/* Measurement switches (no reference counterpart): enable_events = 1 brackets every k_trace<closest>
+ * launch (the dominant kernel) with HIP events on the stream it is launched on, 2 brackets every stage
+ * (summed into mi355pt_stats.*_ms at the next sync; with 2 the visibility stage, which runs beside the
+ * next bounce's closest-hit trace on a second stream, is bracketed on that stream), 0 none;
  * count_work selects the kernel builds that count BVH node records and triangle records fetched. */
 int mi355pt_render_set_profiling(mi355pt_render* render, int enable_events, int count_work);
+
+/* Scheduling switch (no reference counterpart).  From bounce `from_bounce` on, the visibility traces and the
+ * connect step of bounce b run on a second stream beside the closest-hit trace of bounce b + 1 (disjoint state;
+ * shade(b + 1) waits for connect(b)).  Default 0 = every bounce; a value >= max_bounces runs every kernel back to
+ * back on one stream.  Results do not depend on it.  Takes effect at the next render_step. */
+int mi355pt_render_set_overlap(mi355pt_render* render, uint32_t from_bounce);
 
 /* The stream (hipStream_t) the renderer launches on, for callers that time kernels
  * with their own HIP events.                                                        */

@@ -102,7 +102,7 @@ SYMBOLS = [
     "mi355pt_render_create", "mi355pt_render_destroy", "mi355pt_render_step", "mi355pt_render_sync",
     "mi355pt_render_read_rgb8", "mi355pt_render_read_accum", "mi355pt_render_write_accum",
     "mi355pt_render_accum_device_ptrs", "mi355pt_trace_primary", "mi355pt_trace_rays", "mi355pt_sample_radiance",
-    "mi355pt_render_stats", "mi355pt_render_reset_stats", "mi355pt_render_set_profiling", "mi355pt_render_stream",
+    "mi355pt_render_stats", "mi355pt_render_reset_stats", "mi355pt_render_set_profiling", "mi355pt_render_set_overlap", "mi355pt_render_stream",
 ]
 
 _lib = None
@@ -144,6 +144,7 @@ def load_library(path=None):
     lib.mi355pt_render_stats.argtypes = [vp, C.POINTER(Stats)]
     lib.mi355pt_render_reset_stats.argtypes = [vp]
     lib.mi355pt_render_set_profiling.argtypes = [vp, C.c_int, C.c_int]
+    lib.mi355pt_render_set_overlap.argtypes = [vp, C.c_uint32]
     lib.mi355pt_render_stream.argtypes = [vp]
     lib.mi355pt_render_stream.restype = vp
     if path is None:

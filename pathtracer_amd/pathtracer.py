@@ -166,7 +166,13 @@ class PathTracer:
         return lin, mp
 
     def set_profiling(self, events=True, count_work=False):
-        capi.check(self.lib, self.lib.mi355pt_render_set_profiling(self.h, int(events), int(count_work)), "set_profiling")
+        """events: False/0 none, 1 = HIP events around the closest-hit trace launches only, True/2 = around every stage."""
+        level = 2 if events is True else int(events)
+        capi.check(self.lib, self.lib.mi355pt_render_set_profiling(self.h, level, int(count_work)), "set_profiling")
+
+    def set_overlap(self, from_bounce=0):
+        """Bounce from which visibility + connect run beside the next bounce's closest-hit trace (include/mi355pt.h)."""
+        capi.check(self.lib, self.lib.mi355pt_render_set_overlap(self.h, int(from_bounce)), "set_overlap")
 
     def stats(self):
         st = capi.Stats()

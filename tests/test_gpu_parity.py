@@ -179,6 +179,28 @@ def test_traversal_schedule_same_results(built, name, monkeypatch):
     p2.close_render()
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["teapot_cornell", "textured_c2"])
+def test_stream_overlap_same_results(built, name):
+    """Visibility + connect of bounce b beside the closest-hit trace of bounce b + 1 (two streams, the default) against
+    every kernel back to back on one stream: same accumulators bit for bit, same ray counts."""
+    s, orc, pt, w, h = built(name)
+    out = []
+    for from_bounce in (0, 2, 1 << 30):
+        p2 = PathTracer(pt.dscene)
+        p2.Init(w, h)
+        p2.set_overlap(from_bounce)
+        p2.step(3)
+        p2.sync()
+        mean, cnt = p2.read_accum()
+        st = p2.stats()
+        out.append((mean.copy(), cnt.copy(), st["closest_rays"], st["shadow_rays"]))
+        p2.close_render()
+    for o in out[1:]:
+        assert np.array_equal(out[0][0].view(np.uint32), o[0].view(np.uint32))
+        assert np.array_equal(out[0][1], o[1]) and out[0][2:] == o[2:]
+
+
 def test_full_size_10m_triangle_scene(monkeypatch):
     """BASELINE configs[3] at full size (10 036 800 triangles, 3840x2160): primary hits on crops against
     the oracle's exhaustive reference-order walk, and order independence of secondary rays."""

@@ -8,6 +8,6 @@ for c in "c1 512 512" "c2 1920 1080" "c3 3840 2160"; do
 import json, sys
 d = json.load(open(f"gpurun_out/bench_{sys.argv[1]}.json"))
 print(sys.argv[1], round(d["value"], 1), "Mrays/s", round(d["ms_per_step"], 3), "ms/step", round(d["samples_per_pixel_per_s"], 1), "spp/s",
-      {k: round(v / 8, 2) for k, v in d["kernel_ms"].items()}, "frac", round(d["roofline"]["frac"], 3), "nodes/ray", round(d["roofline"]["n_node_per_ray"], 1))
+      {k: round(v, 2) for k, v in d["kernel_ms"].items() if k != "steps"}, "frac", round(d["roofline"]["frac"], 3), "nodes/ray", round(d["roofline"]["n_node_per_ray"], 1))
 PY
 done
