@@ -989,6 +989,10 @@ int mi355pt_scene_create(const mi355pt_scene_desc* desc, int32_t device, mi355pt
         inst_of_node[i] = (int)insts.size();
         insts.push_back(in);
     }
+    for (unsigned v = 0; v < 256; v++) {                     // u8_unorm_selftest (pt_shade.h): the division-free byte -> float is exact
+        volatile float q = (float)v / 255.0f;
+        if (ptd::u8_unorm(v) != q) return fail(MI355PT_ERR_HIP, "u8_unorm differs from v / 255.0f");
+    }
     // ---- lights
     std::vector<DLight> lights(desc->num_lights);
     for (uint32_t i = 0; i < desc->num_lights; i++) {
@@ -1226,18 +1230,33 @@ int mi355pt_render_create(mi355pt_scene* scene, const mi355pt_render_params* par
     HIP_TRY(hipMemsetAsync(r->mean, 0, npix * 12, r->stream)); HIP_TRY(hipMemsetAsync(r->cnt, 0, npix * 4, r->stream));
     HIP_TRY(hipMemsetAsync(r->rgb8, 0, npix * 3, r->stream));
     HIP_TRY(hipStreamSynchronize(r->stream));
-    if (params->tile_size > 0 && params->tile_stride > 1) {
-        // image-tile partition (north_star multi-GPU): tile k of the row-major tile grid belongs to the renderer with
+    {
+        // The pixels this renderer renders, in the order its path slots take them: 8x8 blocks, so that the 64 lanes of
+        // a wave start on a square of the image rather than a 64x1 strip (primary rays and bounce-0 texture footprints
+        // of a wave stay close together).  A pixel's result does not depend on its slot.
+        // Image-tile partition (north_star multi-GPU): tile k of the row-major tile grid belongs to the renderer with
         // k % tile_stride == tile_offset -- interleaved, like the reference's strided workers (pathtracer.cpp:66-109)
-        if (params->tile_offset >= params->tile_stride) return fail(MI355PT_ERR_INVALID, "tile_offset must be < tile_stride");
-        const uint32_t ts = params->tile_size, tx = (params->width + ts - 1) / ts;
+        const bool split = params->tile_size > 0 && params->tile_stride > 1;
+        if (split && params->tile_offset >= params->tile_stride) return fail(MI355PT_ERR_INVALID, "tile_offset must be < tile_stride");
+        const uint32_t ts = split ? params->tile_size : 1u, tx = (params->width + ts - 1) / ts;
+        const uint32_t bs = getenv("MI355PT_LINEAR_ORDER") ? 1u : 8u;     // test knob: 1 = row-major pixel order
         std::vector<uint32_t> own;
-        for (uint32_t y = 0; y < params->height; y++)
-            for (uint32_t x = 0; x < params->width; x++)
-                if (((y / ts) * tx + x / ts) % params->tile_stride == params->tile_offset) own.push_back(y * params->width + x);
-        r->n_own = own.size();
-        HIP_TRY(dalloc((void**)&r->own, std::max<size_t>(own.size(), 1) * 4));
-        if (!own.empty()) HIP_TRY(hipMemcpy(r->own, own.data(), own.size() * 4, hipMemcpyHostToDevice));
+        own.reserve(npix);
+        auto block = [&](uint32_t x0, uint32_t y0, uint32_t x1, uint32_t y1) {
+            for (uint32_t y = y0; y < y1; y++)
+                for (uint32_t x = x0; x < x1; x++)
+                    if (!split || ((y / ts) * tx + x / ts) % params->tile_stride == params->tile_offset) own.push_back(y * params->width + x);
+        };
+        if (bs == 1) block(0, 0, params->width, params->height);
+        else
+            for (uint32_t y0 = 0; y0 < params->height; y0 += bs)
+                for (uint32_t x0 = 0; x0 < params->width; x0 += bs)
+                    block(x0, y0, std::min(x0 + bs, params->width), std::min(y0 + bs, params->height));
+        if (split || bs != 1) {
+            r->n_own = own.size();
+            HIP_TRY(dalloc((void**)&r->own, std::max<size_t>(own.size(), 1) * 4));
+            if (!own.empty()) HIP_TRY(hipMemcpy(r->own, own.data(), own.size() * 4, hipMemcpyHostToDevice));
+        }
     }
     hipDeviceProp_t prop; HIP_TRY(hipGetDeviceProperties(&prop, scene->device));
     r->grid = prop.multiProcessorCount * 8;

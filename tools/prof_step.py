@@ -1,11 +1,15 @@
-"""One short run of the C4 workload for rocprofv3 (kernel trace or --pmc passes)."""
-import sys, os
+"""One short run of a bench workload (default C4) for rocprofv3 (kernel trace or --pmc passes).
+Usage: prof_step.py [max_bounces] [steps] [workload c1..c4]"""
+import sys, os, argparse
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from pathtracer_amd import PathTracer, DeviceScene, scenes
+import bench
+from pathtracer_amd import PathTracer, DeviceScene
 mb = int(sys.argv[1]) if len(sys.argv) > 1 else 2
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 1
-w, h = 3840, 2160
-pt = PathTracer(DeviceScene(scenes.grid_c4(205, 204, w, h)), max_bounces=mb)
+wl = sys.argv[3] if len(sys.argv) > 3 else "c4"
+w, h = {"c1": (512, 512), "c2": (1920, 1080)}.get(wl, (3840, 2160))
+scene, _ = bench.build_scene(argparse.Namespace(workload=wl, grid=[205, 204], tris=0, width=w, height=h, seed=0x5EED))
+pt = PathTracer(DeviceScene(scene) if not isinstance(scene, DeviceScene) else scene, max_bounces=mb)
 pt.Init(w, h)
 for _ in range(steps):
     pt.render(1)
