@@ -101,10 +101,13 @@ typedef struct mi355pt_mesh {
 } mi355pt_mesh;
 
 /* One Model = a run of meshes (reference include/model.h:16-354).                   */
+#define MI355PT_MODEL_HAS_CDF 1u   /* Model::BuildCDFAndArea ran (MeshBuilder models, meshbuilder.h:190,247;
+                                    * ModelLoader never calls it): Model::cdf holds the mesh areas             */
 typedef struct mi355pt_model {
     int32_t first_mesh;
     int32_t num_meshes;
     float   aabb[6];            /* Model::aabb                                         */
+    uint32_t flags;             /* MI355PT_MODEL_*; read for models that carry a light */
 } mi355pt_model;
 
 /* TextureMap (reference include/scene.h:210-248): a Transformation + texture.      */
@@ -136,7 +139,15 @@ typedef struct mi355pt_material {
     float   clearcoat, clearcoat_gloss, subsurface;
 } mi355pt_material;
 
-/* LightComponent (reference include/lightcomponent.h:8-20).                         */
+/* LightComponent (reference include/lightcomponent.h:8-20).  `node` must carry an object; what
+ * Object::Sample / Area give for it is reproduced as the reference computes it:
+ *   Plane   uniform point of the square, its world area (objects.cpp:474-503);
+ *   Sphere  no override: the point (0,0,0) with normal (0,0,0), untransformed, and area 0 (objbase.h:31-39,
+ *           objbase.cpp:5-9), so every pdf is infinite and the direct term NaN -> the sample is black (render.h:218);
+ *   Model   Model::Sample / Area (model.h:57-76): the mesh comes from Model::cdf (one rand() when
+ *           MI355PT_MODEL_HAS_CDF, else mesh 0 and no draw), the point is ALWAYS on face 0 of that mesh because
+ *           BuildCDFAndArea fills the face CDFs of copies (model.h:51), area = |X||Y| scale x the cdf total
+ *           (0 without MI355PT_MODEL_HAS_CDF -- the Sphere case again).                                    */
 typedef struct mi355pt_light {
     int32_t node;               /* LightComponent::parent                              */
     float   intensity[3];

@@ -196,6 +196,7 @@ struct Scene {
     std::vector<mi355pt_texmap> texmaps;
     std::vector<Texture> textures;
     std::vector<mi355pt_light> lights;
+    std::vector<std::vector<float>> model_cd;   // Model::cdf->cd of every model (BuildModelCdf), built with the scene
     V3 env_color; int env_map;
     mi355pt_camera camera;
     int traversal_mode = 0;          // 0 = reference (exhaustive), 1 = ordered + pruned
@@ -1024,22 +1025,77 @@ V3 MaterialEvalBrdf(const Scene& sc, const HitInfo& h, V3 wi, V3 wo, V3& shading
 
 // ------------------------------------------------------------------ lights
 inline V3 LightLe(const Scene& sc, int li) { const float* c = sc.lights[li].intensity; return v3(c[0], c[1], c[2]); } // lightcomponent.cpp:5-8
-// src/objects.cpp:496-503 (Plane::Area); Model::Area etc. are SURVEY 8(f) "next"
+// Object::Area (objbase.h:37-39 -> 0 for Sphere), Plane::Area (objects.cpp:496-503), Model::Area (model.h:57-67)
+// include/mesh.h:63-71
+inline float FaceArea(const Mesh& mesh, size_t faceId) {
+    const uint32_t* f = &mesh.faces[4 * faceId];
+    V3 p0 = mesh.vertices[f[0]], p1 = mesh.vertices[f[1]], p2 = mesh.vertices[f[2]];
+    V3 c = g_cross(p1 - p0, p2 - p0);
+    return 0.5f * sqrtf(g_dot(c, c));                  // glm::length
+}
+// Model::cdf after BuildCDFAndArea (model.h:47-55, mesh.h:75-83, utils.cpp:221-252): cd = {0, a0, a0+a1, ...}.
+// Without MI355PT_MODEL_HAS_CDF the function never ran: cd = {0}, total = 0.
+struct ModelCdf { std::vector<float> cd; float total; };
+ModelCdf BuildModelCdf(const Scene& sc, const mi355pt_model& model) {
+    ModelCdf c; c.cd.push_back(0.0f); c.total = (+0.0f);
+    if (!(model.flags & MI355PT_MODEL_HAS_CDF)) return c;
+    for (int i = 0; i < model.num_meshes; i++) {
+        const Mesh& mesh = sc.meshes[model.first_mesh + i];
+        float area = 0.0f;                             // Mesh::area of the COPY (model.h:51)
+        for (size_t f = 0; f < mesh.faces.size() / 4; f++) area += FaceArea(mesh, f);
+        c.total += area; c.cd.push_back(c.total);
+    }
+    return c;
+}
+// utils.cpp:227-246 (assert(false) compiled out: falls through to 0)
+int CdfSample(const ModelCdf& c, Rng& rng) {
+    if (c.cd.size() == 1) return 0;
+    float random = rng.U() * c.total;
+    for (size_t i = 1; i < c.cd.size(); i++)
+        if (random <= c.cd[i] && random >= c.cd[i - 1]) return (int)i - 1;
+    return 0;
+}
 float ObjectArea(const Scene& sc, int ni) {
     const mi355pt_node& n = sc.nodes[ni];
+    if (n.object_kind == MI355PT_OBJ_MODEL) {
+        V3 zero = TransformPointToWorld(n, v3(0.0f, 0.0f, 0.0f));
+        V3 width = TransformPointToWorld(n, v3(1.0f, 0.0f, 0.0f));
+        V3 height = TransformPointToWorld(n, v3(0.0f, 1.0f, 0.0f));
+        float scaler = length(width - zero) * length(height - zero);
+        return scaler * sc.model_cd[n.object_index].back();     // cdf->total == the last partial sum (utils.cpp:248-252)
+    }
+    if (n.object_kind != MI355PT_OBJ_PLANE) return 0.0f;
     V3 zero = TransformPointToWorld(n, v3(0.0f, 0.0f, 0.0f));
     V3 width = TransformPointToWorld(n, v3(2.0f, 0.0f, 0.0f));
     V3 height = TransformPointToWorld(n, v3(0.0f, 2.0f, 0.0f));
     return length(width - zero) * length(height - zero);
 }
-// src/objects.cpp:474-486 (Plane::Sample) + src/objbase.cpp:11-15
+// Object::Sample (objbase.cpp:5-9), Plane::Sample (objects.cpp:474-486), Model::Sample (model.h:69-76) with
+// Mesh::Sample / SampleFace (mesh.h:39-61: the stored mesh's own cdf is empty -> face 0, no draw) + objbase.cpp:11-15
 Interaction ObjectSample(const Scene& sc, int ni, Rng& rng) {
     const mi355pt_node& n = sc.nodes[ni];
     Interaction it;
-    float x = rng.U() * 2.0f - 1.0f;
-    float y = rng.U() * 2.0f - 1.0f;
-    it.p = v3(x, y, 0.0f);
-    it.n = v3(0.0f, 0.0f, 1.0f);
+    it.n = v3(0.0f, 0.0f, 0.0f); it.p = v3(0.0f, 0.0f, 0.0f);
+    if (n.object_kind == MI355PT_OBJ_MODEL) {
+        const mi355pt_model& model = sc.models[n.object_index];
+        ModelCdf c; c.cd = sc.model_cd[n.object_index]; c.total = c.cd.back();
+        int meshId = CdfSample(c, rng);
+        const Mesh& mesh = sc.meshes[model.first_mesh + meshId];
+        float u0 = rng.U(), u1 = rng.U();              // UniformSampleTriangle, utils.cpp:201-207
+        float su0 = sqrtf(u0);
+        float b0 = 1.0f - su0, b1 = u1 * su0;
+        const uint32_t* f = &mesh.faces[0];
+        V3 p0 = mesh.vertices[f[0]], p1 = mesh.vertices[f[1]], p2 = mesh.vertices[f[2]];
+        it.p = b0 * p0 + b1 * p1 + (1 - b0 - b1) * p2;
+        it.n = g_normalize(g_cross(p1 - p0, p2 - p0));
+    } else if (n.object_kind == MI355PT_OBJ_PLANE) {
+        float x = rng.U() * 2.0f - 1.0f;
+        float y = rng.U() * 2.0f - 1.0f;
+        it.p = v3(x, y, 0.0f);
+        it.n = v3(0.0f, 0.0f, 1.0f);
+    } else {
+        return it;                                     // Object::Sample: not transformed
+    }
     it.p = TransformPointToWorld(n, it.p);
     it.n = normalized(TransformPointToWorld(n, it.n) - TransformPointToWorld(n, v3(0.0f, 0.0f, 0.0f)));
     return it;
@@ -1420,6 +1476,7 @@ oracle_scene* oracle_scene_create(const mi355pt_scene_desc* d) {
         if (s.kind == MI355PT_TEX_RGB32F && s.data) t.d32.assign((const float*)s.data, (const float*)s.data + n);
     }
     if (d->num_lights) sc.lights.assign(d->lights, d->lights + d->num_lights);
+    for (const mi355pt_model& m : sc.models) sc.model_cd.push_back(BuildModelCdf(sc, m).cd);
     sc.env_color = rd3(d->env_color); sc.env_map = d->env_map;
     sc.camera = d->camera;
     return o;

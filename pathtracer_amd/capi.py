@@ -13,6 +13,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libmi355pt.so")
 
 OK = 0
 OBJ_NONE, OBJ_PLANE, OBJ_SPHERE, OBJ_MODEL = 0, 1, 2, 3
+MODEL_HAS_CDF = 1
 MTL_DISNEY, MTL_STANDARD = 0, 1
 TEX_RGB8, TEX_RGB32F, TEX_CHECKER = 0, 1, 2
 BIGFLOAT = 1.0e30
@@ -38,7 +39,7 @@ class Mesh(C.Structure):
 
 
 class Model(C.Structure):
-    _fields_ = [("first_mesh", i32), ("num_meshes", i32), ("aabb", f32 * 6)]
+    _fields_ = [("first_mesh", i32), ("num_meshes", i32), ("aabb", f32 * 6), ("flags", u32)]
 
 
 class TexMap(C.Structure):

@@ -52,7 +52,9 @@ struct DPaths {
     uint32_t *counts;     // [b] = #paths entering bounce b (b >= 1)
     unsigned long long *svcounts;   // [b] = (#visibility items << 32) | #paths with shadow work at bounce b: one atomic reserves both
     uint32_t *vqueue;     // visibility items of this bounce: slot * 2 + which (0 = light sample, 1 = MIS BRDF sample)
-    uint32_t *vwork;      // [b] = next vqueue index to hand out in k_trace<ANY>
+    uint32_t *vwork;      // [b] = next vqueue index to hand out in k_trace<1>
+    uint32_t *lwork;      // [b] = the same for k_trace<2> (scenes with a light on a Model only)
+    uint4 *lhit;          // [2 x cap] per visibility item: closest hit on the light's own Model (k_trace<2>), layout of `hit`
     uint8_t  *vis;        // [2 x cap] 1 = blocked, per visibility item
     uint32_t *work;       // [b] = next queue index to hand out in k_trace<closest> of bounce b (persistent refill)
     uint32_t *spill;      // per resident wave: kStackSize x 64 dwords, the part of a lane's stack below its LDS window
@@ -175,14 +177,18 @@ __device__ __forceinline__ unsigned long long hit_key(float t, uint32_t slot) {
 __device__ __forceinline__ float key_dist(unsigned long long k) { return (k & 1ull) ? -0.0f : __uint_as_float((uint32_t)(k >> 32)); }
 
 //
-// ANY = false: closest hit of the rays in P.ray (k_extend).  ANY = true: LightVisTest's sweep over the objects that are
-// not the light (raytracer.cpp:99-152) for the visibility items queued by k_shade: an item is blocked by any
-// front-face hit nearer than min(tmax, distance to the light); the walk of a blocked ray is abandoned at once.
-template <bool ANY, bool COUNT>
+// MODE 0 (ANY = false): closest hit of the rays in P.ray (k_extend).  MODE 1 (ANY = true): LightVisTest's sweep over
+// the objects that are not the light (raytracer.cpp:99-152) for the visibility items queued by k_shade: an item is
+// blocked by any front-face hit nearer than min(tmax, distance to the light); the walk of a blocked ray is abandoned
+// at once.  MODE 2 (OWN): LightVisTest's first sweep (raytracer.cpp:67-97) for the items whose light sits on a Model:
+// the closest hit, both sides, on the light's own object only, written to P.lhit for MODE 1 and k_connect -- the same
+// walk as MODE 0 over the light's records.  Plane and Sphere lights are tested analytically in MODE 1's set-up.
+template <int MODE, bool COUNT>
 __global__ void __launch_bounds__(kExtBlock) k_trace(DScene S, DPaths P, Params prm, uint32_t bounce, uint32_t n0) {
-    const uint32_t n = ANY ? (uint32_t)(P.svcounts[bounce] >> 32) : (bounce == 0 ? n0 : P.counts[bounce]);
-    const uint32_t* q = ANY ? P.vqueue : (bounce == 0 ? nullptr : P.queue[bounce & 1]);
-    uint32_t* work = ANY ? &P.vwork[bounce] : &P.work[bounce];
+    constexpr bool ANY = MODE == 1, OWN = MODE == 2;
+    const uint32_t n = MODE ? (uint32_t)(P.svcounts[bounce] >> 32) : (bounce == 0 ? n0 : P.counts[bounce]);
+    const uint32_t* q = MODE ? P.vqueue : (bounce == 0 ? nullptr : P.queue[bounce & 1]);
+    uint32_t* work = OWN ? &P.lwork[bounce] : ANY ? &P.vwork[bounce] : &P.work[bounce];
     extern __shared__ uint32_t sm[];
     const uint32_t lane = threadIdx.x;
     const unsigned long long lt = (1ull << lane) - 1ull;
@@ -199,7 +205,7 @@ __global__ void __launch_bounds__(kExtBlock) k_trace(DScene S, DPaths P, Params 
     // stack of about one entry per level with both children hit: the window is rarely left, and a 16-entry window instead
     // of a full-depth stack is what lets 16 instead of 12 waves share a CU's LDS.
     const uint32_t rmask = prm.stack_entries - 1u;
-    uint32_t* spill = (ANY ? P.spill_any : P.spill) + (size_t)blockIdx.x * kStackSize * 64;
+    uint32_t* spill = (MODE ? P.spill_any : P.spill) + (size_t)blockIdx.x * kStackSize * 64;
 #define PT_STK(i) stk[((i) & rmask) * 64 + lane]
 #define PT_SPILL(i) spill[(i) * 64 + lane]
     WorkCounters wc; wc.nodes = 0; wc.tris = 0;
@@ -208,10 +214,11 @@ __global__ void __launch_bounds__(kExtBlock) k_trace(DScene S, DPaths P, Params 
     float bt = kBig, pabs = 0.0f;
     float best_t = kBig; int best_inst = -1, best_mesh = -1; uint32_t best_slot = 0;      // closest: best over the objects so far
     float bound = 0.0f; uint32_t linst = 0;                                                // any: distance bound, the light's object
+    uint32_t rec_end = (uint32_t)S.num_recs;                                               // own: end of the light's records
     float4* recl = (float4*)(aux + kLdsRec);
     // the ray of an item, already taken into the root node's space (level 0 of every object's chain)
     auto load_world = [&](uint32_t it, Ray& wr) {                // closest: `it` is a path slot; any: slot * 2 + which
-        if (!ANY) {
+        if (MODE == 0) {
             wr.p = xyz(P.ray[2 * (size_t)it]); wr.d = xyz(P.ray[2 * (size_t)it + 1]);
         } else {
             const float4* sh = P.sh + (size_t)(it >> 1) * kShVec;
@@ -267,16 +274,30 @@ __global__ void __launch_bounds__(kExtBlock) k_trace(DScene S, DPaths P, Params 
                             rec = 0; state = LS_SETUP;
                             load_world(slot, wr);
                             if (!ANY) { best_t = kBig; best_inst = -1; best_mesh = -1; best_slot = 0; }
-                            else {
+                            if (OWN) {
+                                const DLight& L = S.lights[__float_as_int(P.sh[(size_t)(slot >> 1) * kShVec + SHV_W1].w)];
+                                if (L.kind != MI355PT_OBJ_MODEL) state = LS_IDLE;       // nothing to do for this item
+                                else { rec = (uint32_t)L.rec; rec_end = (uint32_t)L.rec_end; }
+                            }
+                            if (ANY) {
                                 // (1) the light's own object, both sides: a miss or its back side blocks (raytracer.cpp:67-97,138-145)
                                 const float4* sh = P.sh + (size_t)(slot >> 1) * kShVec;
                                 const float tmax = (slot & 1u) ? kBig : sh[SHV_O].w;
                                 const DLight& L = S.lights[__float_as_int(sh[SHV_W1].w)];
                                 linst = (uint32_t)L.inst;
                                 const float4* R = (uint32_t)L.rec < ncache ? (const float4*)(recl + L.rec * kRecStride) : S.recs + (size_t)L.rec * kRecStride;
-                                const Ray lr = rec_ray(S, R, __float_as_uint(R[0].y), linst, wr, 1u);
-                                float lz; bool front; F3 Pp;
-                                if (!plane_hit(lr.p, lr.d, SIDE_BOTH, lz, front, Pp) || !front) { P.vis[slot] = 1; state = LS_IDLE; }
+                                float lz = 0.0f; bool front = false, hit;
+                                if (L.kind == MI355PT_OBJ_MODEL) {                // found by k_trace<2>
+                                    const uint4 v = P.lhit[slot];
+                                    HitRec mh; mh.t = __uint_as_float(v.x); mh.inst = (int)v.y; mh.mesh = (int)v.z; mh.slot = v.w;
+                                    hit = mh.inst >= 0; lz = mh.t;
+                                    if (hit) { Ray w0; w0.p = xyz(sh[SHV_O]); w0.d = xyz(sh[(slot & 1u) ? SHV_W2 : SHV_W1]); front = model_hit_front(S, L, mh, w0); }
+                                } else {
+                                    const Ray lr = rec_ray(S, R, __float_as_uint(R[0].y), linst, wr, 1u);
+                                    F3 Pp;
+                                    hit = L.kind == MI355PT_OBJ_PLANE ? plane_hit(lr.p, lr.d, SIDE_BOTH, lz, front, Pp) : sphere_hit(lr.p, lr.d, SIDE_BOTH, lz, front, Pp);
+                                }
+                                if (!hit || !front) { P.vis[slot] = 1; state = LS_IDLE; }
                                 else bound = tmax < lz ? tmax : lz;              // (2) blocks iff z < tmax && z < lightZ
                             }
                         } else if (exhausted) state = LS_DONE;
@@ -337,8 +358,9 @@ __global__ void __launch_bounds__(kExtBlock) k_trace(DScene S, DPaths P, Params 
                 };
                 if (state == LS_SETUP) {
                     for (;;) {
-                        if (rec >= (uint32_t)S.num_recs) {
+                        if (rec >= (OWN ? rec_end : (uint32_t)S.num_recs)) {
                             if (ANY) P.vis[slot] = 0;
+                            else if (OWN) P.lhit[slot] = make_uint4(__float_as_uint(best_t), (uint32_t)best_inst, (uint32_t)best_mesh, best_slot);
                             else store_hit(P, slot, best_t, best_inst, best_mesh, best_slot);
                             state = LS_IDLE;
                             break;
@@ -505,8 +527,9 @@ __global__ void __launch_bounds__(kExtBlock) k_trace(DScene S, DPaths P, Params 
                 }
                 rec++; state = LS_SETUP;
             }
-            if (state == LS_SETUP && rec >= (uint32_t)S.num_recs) {      // that was the last object: report now, the lane is idle
+            if (state == LS_SETUP && rec >= (OWN ? rec_end : (uint32_t)S.num_recs)) {      // that was the last object: report now, the lane is idle
                 if (ANY) P.vis[slot] = 0;
+                else if (OWN) P.lhit[slot] = make_uint4(__float_as_uint(best_t), (uint32_t)best_inst, (uint32_t)best_mesh, best_slot);
                 else store_hit(P, slot, best_t, best_inst, best_mesh, best_slot);
                 state = LS_IDLE;
             }
@@ -543,10 +566,10 @@ __global__ void __launch_bounds__(kExtBlock) k_trace(DScene S, DPaths P, Params 
 #undef PT_STK
 #undef PT_SPILL
 #undef PT_PHASE
-    if (COUNT) { wave_add64(wc.nodes, &P.stat[ANY ? 5 : 3]); wave_add64(wc.tris, &P.stat[ANY ? 6 : 4]);
-        if (!ANY && lane == 0) { atomicAdd(&P.stat[8], ck_setup); atomicAdd(&P.stat[9], ck_node); atomicAdd(&P.stat[10], ck_drain); atomicAdd(&P.stat[11], ck_rest);
+    if (COUNT) { wave_add64(wc.nodes, &P.stat[MODE ? 5 : 3]); wave_add64(wc.tris, &P.stat[MODE ? 6 : 4]);
+        if (MODE == 0 && lane == 0) { atomicAdd(&P.stat[8], ck_setup); atomicAdd(&P.stat[9], ck_node); atomicAdd(&P.stat[10], ck_drain); atomicAdd(&P.stat[11], ck_rest);
                                  atomicAdd(&P.stat[12], n_node_it); atomicAdd(&P.stat[13], n_node_act); atomicAdd(&P.stat[14], (n_drain_it << 32) | 0ull); } 
-        if (!ANY && lane == 0) atomicAdd(&P.stat[14], n_drain_act); }
+        if (MODE == 0 && lane == 0) atomicAdd(&P.stat[14], n_drain_act); }
 }
 
 // ---------------------------------------------------------------------- shade
@@ -744,7 +767,12 @@ __global__ void __launch_bounds__(kBlock) k_connect(DScene S, DPaths P, uint32_t
                 const DLight& L = S.lights[__float_as_int(sh[SHV_W1].w)];
                 Ray r; r.p = xyz(sh[SHV_O]); r.d = xyz(w2);
                 F3 lp, ln;
-                light_hit_point(S, r, L, lp, ln);
+                HitRec mh; mh.t = 0.0f; mh.inst = -1; mh.mesh = -1; mh.slot = 0;
+                if (L.kind == MI355PT_OBJ_MODEL) {
+                    const uint4 v = P.lhit[2 * (size_t)slot + 1];
+                    mh.t = __uint_as_float(v.x); mh.inst = (int)v.y; mh.mesh = (int)v.z; mh.slot = v.w;
+                }
+                light_hit_point(S, r, L, mh, lp, ln);
                 const F3 hp = xyz(hpf);
                 const float lightPdf = light_pdf(L, hp, lp, ln, len(lp - hp));
                 if (!(lightPdf <= 0.0f)) {
@@ -869,13 +897,14 @@ struct mi355pt_scene {
     std::vector<ptb::MeshTree> trees;
     DevBuf<DNodeXf> nodes; DevBuf<DInst> insts; DevBuf<DModel> models; DevBuf<DMesh> meshes;
     DevBuf<float4> bvh_nodes, tris, recs; DevBuf<uint32_t> faces; DevBuf<float> normals, uvw, tangents, bitangents;
-    DevBuf<mi355pt_material> materials; DevBuf<mi355pt_texmap> texmaps; DevBuf<DTexture> textures; DevBuf<DLight> lights;
+    DevBuf<mi355pt_material> materials; DevBuf<mi355pt_texmap> texmaps; DevBuf<DTexture> textures; DevBuf<DLight> lights; DevBuf<float> light_data;
+    bool model_lights = false;        // some light sits on a Model: its own-object test is a BVH traversal (k_trace<2>)
     std::vector<void*> tex_data;
     uint64_t num_tris = 0, num_bvh_nodes = 0; int max_depth = 0;
     ~mi355pt_scene() {
         nodes.release(); insts.release(); models.release(); meshes.release(); bvh_nodes.release(); tris.release(); recs.release(); faces.release();
         normals.release(); uvw.release(); tangents.release(); bitangents.release(); materials.release(); texmaps.release();
-        textures.release(); lights.release();
+        textures.release(); lights.release(); light_data.release();
         for (void* p : tex_data) (void)hipFree(p);
     }
 };
@@ -994,17 +1023,56 @@ int mi355pt_scene_create(const mi355pt_scene_desc* desc, int32_t device, mi355pt
         if (ptd::u8_unorm(v) != q) return fail(MI355PT_ERR_HIP, "u8_unorm differs from v / 255.0f");
     }
     // ---- lights
+    // Object::Sample / Area of the light's object as the reference computes them (include/mi355pt.h, mi355pt_light)
     std::vector<DLight> lights(desc->num_lights);
+    std::vector<float> light_data;
+    bool model_lights = false;
     for (uint32_t i = 0; i < desc->num_lights; i++) {
         const mi355pt_light& s = desc->lights[i];
-        if (s.node < 0 || (uint32_t)s.node >= desc->num_nodes || desc->nodes[s.node].object_kind != MI355PT_OBJ_PLANE)
-            return fail(MI355PT_ERR_UNSUPPORTED, "lights must sit on Plane nodes (mesh lights are a later row)");
+        if (s.node < 0 || (uint32_t)s.node >= desc->num_nodes || desc->nodes[s.node].object_kind == MI355PT_OBJ_NONE)
+            return fail(MI355PT_ERR_INVALID, "a light's node must carry an object (LightComponent::parent->GetNodeObj())");
+        const mi355pt_node& ln = desc->nodes[s.node];
         DLight& d = lights[i];
-        d.node = s.node; memcpy(d.intensity, s.intensity, sizeof(d.intensity)); d.inst = inst_of_node[s.node]; d.rec = 0; d.pad1 = 0;
-        const float* m = desc->nodes[s.node].local_to_world;       // Plane::Area, objects.cpp:496-503
-        const H3 zero = h_m4mulp(m, H3{0, 0, 0}, 1.0f), wv = h_m4mulp(m, H3{2, 0, 0}, 1.0f), hv = h_m4mulp(m, H3{0, 2, 0}, 1.0f);
-        d.area = h_len(H3{wv.x - zero.x, wv.y - zero.y, wv.z - zero.z}) * h_len(H3{hv.x - zero.x, hv.y - zero.y, hv.z - zero.z});
+        memset(&d, 0, sizeof(d));
+        d.node = s.node; memcpy(d.intensity, s.intensity, sizeof(d.intensity)); d.inst = inst_of_node[s.node]; d.kind = ln.object_kind;
+        const float* m = ln.local_to_world;
+        auto span = [&](float e) {                                // |X| * |Y| of the node's local axes scaled by e, in world space
+            const H3 zero = h_m4mulp(m, H3{0, 0, 0}, 1.0f), wv = h_m4mulp(m, H3{e, 0, 0}, 1.0f), hv = h_m4mulp(m, H3{0, e, 0}, 1.0f);
+            return h_len(H3{wv.x - zero.x, wv.y - zero.y, wv.z - zero.z}) * h_len(H3{hv.x - zero.x, hv.y - zero.y, hv.z - zero.z});
+        };
+        if (ln.object_kind == MI355PT_OBJ_PLANE) d.area = span(2.0f);            // Plane::Area, objects.cpp:496-503
+        else if (ln.object_kind == MI355PT_OBJ_SPHERE) d.area = 0.0f;            // Object::Area, objbase.h:37-39
+        else {                                                                   // Model::Area, model.h:57-67
+            if (ln.object_index < 0 || (uint32_t)ln.object_index >= desc->num_models) return fail(MI355PT_ERR_INVALID, "bad model index");
+            const mi355pt_model& mo = desc->models[ln.object_index];
+            if (mo.first_mesh < 0 || mo.num_meshes < 1 || (uint32_t)(mo.first_mesh + mo.num_meshes) > desc->num_meshes) return fail(MI355PT_ERR_INVALID, "a light's model needs at least one mesh");
+            model_lights = true;
+            d.data = (int)light_data.size();
+            float total = (+0.0f);
+            light_data.push_back(0.0f); d.n_cd = 1;
+            std::vector<float> face0;
+            for (int k = 0; k < mo.num_meshes; k++) {
+                const mi355pt_mesh& me = desc->meshes[mo.first_mesh + k];
+                if (!me.vertices || !me.faces || me.num_faces < 1) return fail(MI355PT_ERR_INVALID, "a light's meshes need at least one face (Mesh::SampleFace(0))");
+                auto vert = [&](uint32_t f, int c) { const uint32_t v = me.faces[4 * (size_t)f + c]; return H3{me.vertices[3 * (size_t)v], me.vertices[3 * (size_t)v + 1], me.vertices[3 * (size_t)v + 2]}; };
+                for (uint32_t f = 0; f < me.num_faces; f++) for (int c = 0; c < 3; c++) if (me.faces[4 * (size_t)f + c] >= me.num_vertices) return fail(MI355PT_ERR_INVALID, "face index out of range");
+                if (mo.flags & MI355PT_MODEL_HAS_CDF) {          // BuildCDFAndArea, model.h:47-55 / mesh.h:63-83 (glm cross, length)
+                    float area = 0.0f;
+                    for (uint32_t f = 0; f < me.num_faces; f++) {
+                        const H3 p0 = vert(f, 0), p1 = vert(f, 1), p2 = vert(f, 2);
+                        const H3 x = H3{p1.x - p0.x, p1.y - p0.y, p1.z - p0.z}, y = H3{p2.x - p0.x, p2.y - p0.y, p2.z - p0.z};
+                        const H3 c = H3{x.y * y.z - y.y * x.z, x.z * y.x - y.z * x.x, x.x * y.y - y.x * x.y};
+                        area += 0.5f * sqrtf(c.x * c.x + c.y * c.y + c.z * c.z);
+                    }
+                    total += area; light_data.push_back(total); d.n_cd++;
+                }
+                for (int c = 0; c < 3; c++) { const H3 p = vert(0, c); face0.push_back(p.x); face0.push_back(p.y); face0.push_back(p.z); }
+            }
+            light_data.insert(light_data.end(), face0.begin(), face0.end());
+            d.area = span(1.0f) * total;
+        }
     }
+    sc->model_lights = model_lights;
     // ---- meshes: BVH build / import, flatten, pack
     std::vector<DModel> models(desc->num_models);
     for (uint32_t i = 0; i < desc->num_models; i++) {
@@ -1103,7 +1171,7 @@ int mi355pt_scene_create(const mi355pt_scene_desc* desc, int32_t device, mi355pt
         }
     }
     inst_rec[insts.size()] = (int)(recs.size() / kRecStride);
-    for (auto& L : lights) L.rec = L.inst >= 0 ? inst_rec[L.inst] : 0;
+    for (auto& L : lights) { L.rec = L.inst >= 0 ? inst_rec[L.inst] : 0; L.rec_end = L.inst >= 0 ? inst_rec[L.inst + 1] : 0; }
     // ---- materials / textures
     std::vector<mi355pt_material> materials(desc->materials, desc->materials + desc->num_materials);
     std::vector<mi355pt_texmap> texmaps(desc->texmaps, desc->texmaps + desc->num_texmaps);
@@ -1134,12 +1202,12 @@ int mi355pt_scene_create(const mi355pt_scene_desc* desc, int32_t device, mi355pt
     HIP_TRY(sc->bvh_nodes.upload(bvh_nodes)); HIP_TRY(sc->tris.upload(tris)); HIP_TRY(sc->faces.upload(faces));
     HIP_TRY(sc->normals.upload(normals)); HIP_TRY(sc->uvw.upload(uvw)); HIP_TRY(sc->tangents.upload(tangents)); HIP_TRY(sc->bitangents.upload(bitangents));
     HIP_TRY(sc->recs.upload(recs));
-    HIP_TRY(sc->materials.upload(materials)); HIP_TRY(sc->texmaps.upload(texmaps)); HIP_TRY(sc->textures.upload(textures)); HIP_TRY(sc->lights.upload(lights));
+    HIP_TRY(sc->materials.upload(materials)); HIP_TRY(sc->texmaps.upload(texmaps)); HIP_TRY(sc->textures.upload(textures)); HIP_TRY(sc->lights.upload(lights)); HIP_TRY(sc->light_data.upload(light_data));
     DScene& d = sc->d;
     d.nodes = sc->nodes.p; d.num_nodes = (int)nodes.size(); d.insts = sc->insts.p; d.num_insts = (int)insts.size();
     d.models = sc->models.p; d.meshes = sc->meshes.p; d.bvh_nodes = sc->bvh_nodes.p; d.tris = sc->tris.p; d.faces = sc->faces.p;
     d.normals = sc->normals.p; d.uvw = sc->uvw.p; d.tangents = sc->tangents.p; d.bitangents = sc->bitangents.p;
-    d.materials = sc->materials.p; d.texmaps = sc->texmaps.p; d.textures = sc->textures.p; d.lights = sc->lights.p; d.num_lights = (int)lights.size();
+    d.materials = sc->materials.p; d.texmaps = sc->texmaps.p; d.textures = sc->textures.p; d.lights = sc->lights.p; d.num_lights = (int)lights.size(); d.light_data = sc->light_data.p;
     d.recs = sc->recs.p; d.num_recs = (int)(recs.size() / kRecStride);
     memcpy(d.env_color, desc->env_color, sizeof(d.env_color)); d.env_map = desc->env_map;
     for (int i = 0; i < 32; i++) {      // Texture::Sample tap offsets (scene.h:169-175), host libm like the reference
@@ -1221,7 +1289,8 @@ int mi355pt_render_create(mi355pt_scene* scene, const mi355pt_render_params* par
     HIP_TRY(dalloc((void**)&P.queue[0], cap * 4)); HIP_TRY(dalloc((void**)&P.queue[1], cap * 4)); HIP_TRY(dalloc((void**)&P.squeue, cap * 4));
     const size_t nb = params->max_bounces + 2;
     HIP_TRY(dalloc((void**)&P.counts, nb * 4)); HIP_TRY(dalloc((void**)&P.svcounts, nb * 8)); HIP_TRY(dalloc((void**)&P.work, nb * 4));
-    HIP_TRY(dalloc((void**)&P.vqueue, cap * 8)); HIP_TRY(dalloc((void**)&P.vwork, nb * 4));
+    HIP_TRY(dalloc((void**)&P.vqueue, cap * 8)); HIP_TRY(dalloc((void**)&P.vwork, nb * 4)); HIP_TRY(dalloc((void**)&P.lwork, nb * 4));
+    if (scene->model_lights) HIP_TRY(dalloc((void**)&P.lhit, cap * 2 * sizeof(uint4)));
     HIP_TRY(dalloc((void**)&P.vis, cap * 2));
     HIP_TRY(dalloc((void**)&P.stat, 16 * sizeof(unsigned long long)));
     HIP_TRY(hipMemsetAsync(P.stat, 0, 16 * sizeof(unsigned long long), r->stream));
@@ -1268,7 +1337,7 @@ int mi355pt_render_create(mi355pt_scene* scene, const mi355pt_render_params* par
         r->stack_entries = (uint32_t)entries;
         r->extend_lds = extend_lds_bytes((uint32_t)entries);
         int waves = 0;
-        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&waves, k_trace<false, false>, kExtBlock, r->extend_lds));
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&waves, k_trace<0, false>, kExtBlock, r->extend_lds));
         if (const char* e = getenv("MI355PT_EXTEND_WAVES_PER_CU")) waves = std::min(waves, std::max(1, atoi(e)));
         r->extend_grid = prop.multiProcessorCount * std::max(1, waves);
         HIP_TRY(dalloc((void**)&P.spill, (size_t)r->extend_grid * kStackSize * 64 * 4));
@@ -1330,14 +1399,15 @@ int run_paths(mi355pt_render* r, uint32_t n, uint32_t jitter = 1, uint32_t only_
     HIP_TRY(hipMemsetAsync(P.svcounts, 0, nb * 8, r->stream));
     HIP_TRY(hipMemsetAsync(P.work, 0, nb * 4, r->stream));
     HIP_TRY(hipMemsetAsync(P.vwork, 0, nb * 4, r->stream));
+    HIP_TRY(hipMemsetAsync(P.lwork, 0, nb * 4, r->stream));
     const int g = grid_for(r, n);
     const int ge = (int)std::max<size_t>(1, std::min<size_t>(((size_t)n + 63) / 64, (size_t)r->extend_grid));     // persistent: resident waves only
     const int gs = (int)std::max<size_t>(1, std::min<size_t>(((size_t)n + 63) / 64, (size_t)r->grid * 4));       // one wave per workgroup
     if (jitter != 2) hipLaunchKernelGGL(k_raygen, dim3(g), dim3(kBlock), 0, r->stream, r->cam, P, prm, n, jitter);
     auto closest = [&](uint32_t b) {
         ev_begin(r, 0, r->stream);
-        if (r->count_work) hipLaunchKernelGGL((k_trace<false, true>), dim3(ge), dim3(kExtBlock), r->extend_lds, r->stream, S, P, prm, b, n);
-        else hipLaunchKernelGGL((k_trace<false, false>), dim3(ge), dim3(kExtBlock), r->extend_lds, r->stream, S, P, prm, b, n);
+        if (r->count_work) hipLaunchKernelGGL((k_trace<0, true>), dim3(ge), dim3(kExtBlock), r->extend_lds, r->stream, S, P, prm, b, n);
+        else hipLaunchKernelGGL((k_trace<0, false>), dim3(ge), dim3(kExtBlock), r->extend_lds, r->stream, S, P, prm, b, n);
         ev_end(r, r->stream);
     };
     const uint32_t nbounce = only_extend ? 0u : p.max_bounces;
@@ -1358,8 +1428,12 @@ int run_paths(mi355pt_render* r, uint32_t n, uint32_t jitter = 1, uint32_t only_
             HIP_TRY(hipStreamWaitEvent(vs, r->fork[b], 0));
         }
         ev_begin(r, 2, vs);
-        if (r->count_work) hipLaunchKernelGGL((k_trace<true, true>), dim3(ge), dim3(kExtBlock), r->extend_lds, vs, S, P, prm, b, n);
-        else hipLaunchKernelGGL((k_trace<true, false>), dim3(ge), dim3(kExtBlock), r->extend_lds, vs, S, P, prm, b, n);
+        if (r->scene->model_lights) {                       // lights on Models: their own-object sweep first
+            if (r->count_work) hipLaunchKernelGGL((k_trace<2, true>), dim3(ge), dim3(kExtBlock), r->extend_lds, vs, S, P, prm, b, n);
+            else hipLaunchKernelGGL((k_trace<2, false>), dim3(ge), dim3(kExtBlock), r->extend_lds, vs, S, P, prm, b, n);
+        }
+        if (r->count_work) hipLaunchKernelGGL((k_trace<1, true>), dim3(ge), dim3(kExtBlock), r->extend_lds, vs, S, P, prm, b, n);
+        else hipLaunchKernelGGL((k_trace<1, false>), dim3(ge), dim3(kExtBlock), r->extend_lds, vs, S, P, prm, b, n);
         hipLaunchKernelGGL(k_connect, dim3(g), dim3(kBlock), 0, vs, S, P, b);
         ev_end(r, vs);
         if (fork) { HIP_TRY(hipEventRecord(r->join[b], vs)); pending = true; }

@@ -27,7 +27,9 @@ struct DMesh {
     uint32_t has_tangents, pad;
 };
 struct DTexture { int kind, width, height, pad; const void* data; float c1[3], c2[3]; };
-struct DLight { int node; float intensity[3]; float area; int inst; int rec; int pad1; };      // rec: the light object's walk record
+// rec / rec_end: the walk records of the light's object.  Model lights: `data` indexes DScene::light_data, which holds
+// Model::cdf->cd (n_cd partial sums, the first 0) and then the three vertices of face 0 of every mesh (9 floats each).
+struct DLight { int node; float intensity[3]; float area; int inst; int rec; int rec_end; int kind; int data; int n_cd; int pad; };
 struct DCamera {
     float pos[3], up[3], front[3], right[3];
     float plane_h, plane_w, texel_w, texel_h, focaldist, dof;
@@ -59,6 +61,7 @@ struct DScene {
     const mi355pt_texmap*   texmaps;
     const DTexture* textures;
     const DLight*   lights;     int num_lights;
+    const float*    light_data;
     const float4*   recs;       int num_recs;
     float env_color[3];         int env_map;
     float filter_taps[64];           // (x, y) of the 32 elliptic filter taps, scene.h:169-181

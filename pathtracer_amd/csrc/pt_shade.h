@@ -473,12 +473,35 @@ PT_DEV F3 mat_eval(const MatCtx& m, F3 wi, F3 wo) {      // shadingNormal output
 }
 
 // ------------------------------------------------------------------ area light (lightcomponent.cpp, objects.cpp:474-503)
+// Object::Sample of the light's object (objbase.cpp:5-15, objects.cpp:474-486, model.h:69-76 + mesh.h:39-61)
 PT_DEV void light_sample_point(const DScene& S, const DLight& L, Rng& rng, F3& sp, F3& sn) {
     const DNodeXf& n = S.nodes[L.node];
-    const float x = rng.U() * 2.0f - 1.0f;
-    const float y = rng.U() * 2.0f - 1.0f;
-    sp = m4mulp(n.l2w, f3(x, y, 0.0f), 1.0f);
-    sn = normalized(m4mulp(n.l2w, f3(0.0f, 0.0f, 1.0f), 1.0f) - m4mulp(n.l2w, f3(0.0f, 0.0f, 0.0f), 1.0f));
+    F3 p, nn;
+    if (L.kind == MI355PT_OBJ_PLANE) {
+        const float x = rng.U() * 2.0f - 1.0f;
+        const float y = rng.U() * 2.0f - 1.0f;
+        p = f3(x, y, 0.0f); nn = f3(0.0f, 0.0f, 1.0f);
+    } else if (L.kind == MI355PT_OBJ_MODEL) {
+        const float* cd = S.light_data + L.data;
+        int meshId = 0;
+        if (L.n_cd != 1) {                                     // CDF::Sample, utils.cpp:227-246
+            const float random = rng.U() * cd[L.n_cd - 1];
+            for (int i = 1; i < L.n_cd; i++)
+                if (random <= cd[i] && random >= cd[i - 1]) { meshId = i - 1; break; }
+        }
+        const float u0 = rng.U(), u1 = rng.U();                // UniformSampleTriangle, utils.cpp:201-207
+        const float su0 = sqrtf(u0);
+        const float b0 = 1.0f - su0, b1 = u1 * su0;
+        const float* v = cd + L.n_cd + 9 * meshId;             // face 0 of the mesh: the stored mesh's own cdf is empty (model.h:51)
+        const F3 p0 = ld3(v), p1 = ld3(v + 3), p2 = ld3(v + 6);
+        p = b0 * p0 + b1 * p1 + (1.0f - b0 - b1) * p2;
+        nn = gnormalize(gcross(p1 - p0, p2 - p0));
+    } else {                                                   // Object::Sample: the origin, not transformed
+        sp = f3(0.0f, 0.0f, 0.0f); sn = f3(0.0f, 0.0f, 0.0f);
+        return;
+    }
+    sp = m4mulp(n.l2w, p, 1.0f);
+    sn = normalized(m4mulp(n.l2w, nn, 1.0f) - m4mulp(n.l2w, f3(0.0f, 0.0f, 0.0f), 1.0f));
 }
 PT_DEV float light_pdf(const DLight& L, F3 hitp, F3 sp, F3 sn, float distance) {
     const float d2 = distance * distance;
@@ -489,18 +512,36 @@ PT_DEV float light_pdf(const DLight& L, F3 hitp, F3 sp, F3 sn, float distance) {
 
 // First sweep of LightVisTest (raytracer.cpp:67-97): the light's own object, both sides.  Returns true for a
 // front-side hit; lp / ln = the hit point / normal in world space.  (The second sweep, over every other object,
-// is k_trace<ANY> in mi355pt.hip.)
-PT_DEV bool light_hit_point(const DScene& S, const Ray& wr, const DLight& L, F3& lp, F3& ln) {
+// is k_trace<1> in mi355pt.hip.)  A Model's closest hit was found by k_trace<2> and is handed in as `mh`.
+PT_DEV bool light_hit_point(const DScene& S, const Ray& wr, const DLight& L, const HitRec& mh, F3& lp, F3& ln) {
     const DInst& li = S.insts[L.inst];
+    lp = ln = f3(0, 0, 0);
+    Surf h;
+    if (L.kind == MI355PT_OBJ_MODEL) {
+        if (mh.inst < 0) return false;
+        surf_from_hit(S, mh, wr, false, f3(0, 0, 0), f3(0, 0, 0), h);
+        lp = h.p; ln = h.N;
+        return h.front;
+    }
     const Ray lr = to_inst(S, li, wr);
     float lz; bool front; F3 P;
-    lp = ln = f3(0, 0, 0);
-    if (!plane_hit(lr.p, lr.d, SIDE_BOTH, lz, front, P)) return false;
-    Surf h; h.p = P; h.N = front ? f3(0.0f, 0.0f, 1.0f) : -1.0f * f3(0.0f, 0.0f, 1.0f);
-    h.T = f3(1.0f, 0.0f, 0.0f); h.B = f3(0.0f, 1.0f, 0.0f);
+    if (L.kind == MI355PT_OBJ_PLANE) {
+        if (!plane_hit(lr.p, lr.d, SIDE_BOTH, lz, front, P)) return false;
+        h.N = front ? f3(0.0f, 0.0f, 1.0f) : -1.0f * f3(0.0f, 0.0f, 1.0f);
+    } else {
+        if (!sphere_hit(lr.p, lr.d, SIDE_BOTH, lz, front, P)) return false;
+        h.N = front ? P : -1.0f * P;                           // objects.cpp:685-790
+    }
+    h.p = P;
     surf_to_world(S, li, h, false);
     lp = h.p; ln = h.N;
     return front;
+}
+// Front / back of a Model light's recorded closest hit (IntersectRayWithFace, model.h:262-266), for k_trace<1>'s set-up
+PT_DEV bool model_hit_front(const DScene& S, const DLight& L, const HitRec& mh, const Ray& wr) {
+    const Ray lr = to_inst(S, S.insts[L.inst], wr);
+    const Tri T = load_tri(S.tris, mh.slot);
+    return gdot(lr.d, gcross(T.v1 - T.v0, T.v2 - T.v0)) < 0.0f;
 }
 
 // ------------------------------------------------------------------ tone mapping (tonemapping.h:14-42)

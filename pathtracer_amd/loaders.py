@@ -109,7 +109,7 @@ def BuildTextModel(path):
     uvw = np.concatenate([uv, np.zeros((uv.shape[0], 1), dtype=F)], axis=1)
     if not (len(verts) == len(norms) == len(uvw)) or (tris.size and tris.max() >= len(verts)):
         raise SceneFormatError(f"{path}: inconsistent vertex / normal / uv / index counts")
-    return Model([Mesh(verts, norms, uvw, tris)])
+    return Model([Mesh(verts, norms, uvw, tris)], has_cdf=True)       # meshbuilder.h:189-190
 
 
 def LoadModel(path, light=None):

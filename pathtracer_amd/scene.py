@@ -199,8 +199,9 @@ class Model:
     """reference include/model.h: a list of meshes + their union box."""
     kind = capi.OBJ_MODEL
 
-    def __init__(self, meshes):
+    def __init__(self, meshes, has_cdf=False):
         self.meshes = list(meshes)
+        self.has_cdf = bool(has_cdf)      # Model::BuildCDFAndArea ran (MeshBuilder models only)
         mn = np.min([m.aabb[:3] for m in self.meshes], axis=0)
         mx = np.max([m.aabb[3:] for m in self.meshes], axis=0)
         self.aabb = np.concatenate([mn, mx]).astype(F)
@@ -431,6 +432,7 @@ class Scene:
         for i, (mo, first) in enumerate(models):
             cmodels[i].first_mesh, cmodels[i].num_meshes = first, len(mo.meshes)
             cmodels[i].aabb[:] = mo.aabb.tolist()
+            cmodels[i].flags = capi.MODEL_HAS_CDF if mo.has_cdf else 0
         cmeshes = (capi.Mesh * max(1, len(meshes)))()
         fp, up_ = C.POINTER(capi.f32), C.POINTER(capi.u32)
         for i, me in enumerate(meshes):

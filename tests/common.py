@@ -51,7 +51,44 @@ def small_scenes():
         ball.Scale(2.0, 1.5, 2.5); ball.Translate((-6, -14, 14))
         return s
 
+    def quad_mesh(x0, y0, x1, y1, z):
+        return scene.Mesh(np.array([[x0, y0, z], [x1, y0, z], [x1, y1, z], [x0, y1, z]], dtype=np.float32),
+                          np.tile(np.array([[0, 0, -1]], dtype=np.float32), (4, 1)),
+                          np.array([[0, 0, 0], [1, 0, 0], [1, 1, 0], [0, 1, 0]], dtype=np.float32), np.array([[0, 2, 1], [0, 3, 2]]))
+
+    def mesh_light(w, h):
+        """SURVEY 8f-4: a light on a MeshBuilder-style Model (Model::cdf built) of two meshes of different area, under a
+        scaled and rotated node, beside the Cornell box's Plane light; a teapot casts shadows.  The reference samples
+        face 0 of the chosen mesh only (model.h:51) and tests the Model itself, both sides, for visibility."""
+        s = scenes.cornell_c3(w, h, dof=0.0)
+        m = scene.MtlDisney("ml", albedo=(0.85, 0.8, 0.7), roughness=np.float32(0.5), metalness=np.float32(0.05), specular=0.3)
+        me = scene.MtlDisney("emit", roughness=1.0)
+        s.materials += [m, me]
+        panel = scene.Model([quad_mesh(-2, -1, 0, 1, 0.0), quad_mesh(0.5, -1.5, 3.5, 1.5, 0.25)], has_cdf=True)
+        ln = s.rootNode.AppendChild(scene.Node("panel", panel, me, light=scene.LightComponent((9.0, 8.0, 6.0))))
+        ln.Scale(1.5, 2.0, 1.0); ln.Rotate((0, 1, 0), 25.0); ln.Translate((-6, -4, 15))
+        tp = scene.load_obj(os.path.join(ASSETS, "teapot_lowpoly.obj"))
+        tp = scene.Mesh((tp.vertices * np.float32(0.1)).astype(np.float32), tp.normals, tp.uvw, tp.faces[:, :3])
+        t = s.rootNode.AppendChild(scene.Node("teapot", scene.Model([tp]), m))
+        t.Rotate((0, 0, 1), 40.0); t.Translate((-5, -3, 6))
+        return s
+
+    def dead_lights(w, h):
+        """Lights whose Object::Area() is 0 in the reference: a Sphere (no Sample / Area override) and an imported Model
+        (ModelLoader never builds Model::cdf).  Their pdf is infinite and the MIS weight NaN, so a path that picks one
+        at a vertex where the light is visible ends black (render.h:218-223); the Plane light still works."""
+        s = scenes.cornell_c3(w, h, dof=0.0)
+        me = scene.MtlDisney("emit", roughness=1.0)
+        s.materials.append(me)
+        b = s.rootNode.AppendChild(scene.Node("bulb", scene.Sphere(), me, light=scene.LightComponent((4.0, 4.0, 4.0))))
+        b.Scale(1.5); b.Translate((5, -5, 12))
+        q = s.rootNode.AppendChild(scene.Node("import", scene.Model([quad_mesh(-1, -1, 1, 1, 0.0)]), me, light=scene.LightComponent((5.0, 5.0, 5.0))))
+        q.Scale(2.0); q.Translate((-5, -6, 16))
+        return s
+
     return {
+        "mesh_light": (mesh_light, 96, 72),
+        "dead_lights": (dead_lights, 64, 48),
         "cornell_c1": (lambda w, h: scenes.cornell_c1(w, h), 96, 96),
         "cornell_c3_dof": (lambda w, h: scenes.cornell_c3(w, h, dof=0.5), 96, 64),
         "teapot_cornell": (teapot_cornell, 96, 72),

@@ -91,6 +91,33 @@ def test_light_attribute_forms(tmp_path):
         loaders.LoadScene(str(p))
 
 
+def test_lights_on_models_and_spheres(monkeypatch):
+    """SURVEY 8f-4: `light=` on a textmodel / model / sphere object.  MeshBuilder models carry Model::cdf
+    (meshbuilder.h:190), imported ones do not (model.h:356-424); the flag travels in mi355pt_model.flags."""
+    monkeypatch.chdir(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    base = open(os.path.join(SC, "nested_models.xml")).read()
+    txt = base.replace('type="textmodel" name="quad.model" material="red"', 'type="textmodel" name="quad.model" material="red" light="3 2 1"')
+    txt = txt.replace('material="gold">', 'material="gold" light="0.6">')
+    import tempfile
+    with tempfile.NamedTemporaryFile("w", suffix=".xml", dir=SC, delete=False) as f:
+        f.write(txt)
+    try:
+        s = loaders.LoadScene(f.name)
+    finally:
+        os.unlink(f.name)
+    d, keep = s.to_desc()
+    assert d.num_lights == 3
+    kinds = [d.nodes[d.lights[i].node].object_kind for i in range(3)]
+    assert sorted(kinds) == [capi.OBJ_PLANE, capi.OBJ_MODEL, capi.OBJ_MODEL]
+    flags = {d.nodes[d.lights[i].node].object_index: d.models[d.nodes[d.lights[i].node].object_index].flags
+             for i in range(3) if d.nodes[d.lights[i].node].object_kind == capi.OBJ_MODEL}
+    assert sorted(flags.values()) == [0, capi.MODEL_HAS_CDF]
+    # the imported model's light ends on the node that carries the mesh (ModelLoader::ProcessNode, model.h:390)
+    imported = [i for i in range(3) if d.nodes[d.lights[i].node].object_kind == capi.OBJ_MODEL
+                and d.models[d.nodes[d.lights[i].node].object_index].flags == 0][0]
+    assert tuple(d.lights[imported].intensity) == pytest.approx((0.6, 0.6, 0.6))
+
+
 def test_errors(tmp_path):
     base = open(os.path.join(SC, "cornell_c1.xml")).read()
     p = tmp_path / "e.xml"

@@ -21,7 +21,7 @@ def per_launch(db, counter, pattern):
 if __name__ == "__main__":
     fetch_db, write_db, tag = sys.argv[1:4]
     out = {"source": f"profiles/{tag}_pmc_fetch_size.csv, profiles/{tag}_pmc_write_size.csv (tools/gpu_measure.sh {tag})"}
-    for key, pat in (("k_trace_closest", "%k_trace<false%"), ("k_trace_any", "%k_trace<true%"), ("k_shade", "k_shade%")):
+    for key, pat in (("k_trace_closest", "%k_trace<0%"), ("k_trace_any", "%k_trace<1%"), ("k_shade", "k_shade%")):
         f, n = per_launch(fetch_db, "FETCH_SIZE", pat)
         w, _ = per_launch(write_db, "WRITE_SIZE", pat)
         out[key + "_fetch_kib_raw"] = f

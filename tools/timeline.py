@@ -5,6 +5,6 @@ rows = c.execute("select name, start, end from kernels order by start").fetchall
 last = max(i for i, r in enumerate(rows) if r[0].startswith("k_raygen"))
 out = []
 for n, s, e in rows[last:]:
-    short = 'ext' if 'k_trace<false' in n else 'vis' if 'k_trace<true' in n else n.split('(')[0][:9]
+    short = 'ext' if ('k_trace<false' in n or 'k_trace<0' in n) else 'vis' if ('k_trace<true' in n or 'k_trace<1' in n) else 'own' if 'k_trace<2' in n else n.split('(')[0][:9]
     out.append(f"{short}:{(e - s) / 1000:.0f}")
 print(' '.join(out))
