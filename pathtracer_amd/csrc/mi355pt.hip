@@ -16,6 +16,7 @@
 #include <memory>
 #include <mutex>
 #include <string>
+#include <chrono>
 #include <thread>
 #include <vector>
 
@@ -54,6 +55,8 @@ struct DPaths {
     uint32_t *vqueue;     // visibility items of this bounce: slot * 2 + which (0 = light sample, 1 = MIS BRDF sample)
     uint32_t *vwork;      // [b] = next vqueue index to hand out in k_trace<1>
     uint32_t *lwork;      // [b] = the same for k_trace<2> (scenes with a light on a Model only)
+    unsigned long long *progress;   // host-visible (pinned): [b] = (run generation << 32) | (paths queued for bounce b) + 1, written
+                                    // when k_trace<0>(b) starts; the host stops enqueuing bounces once a bounce had no path left
     uint4 *lhit;          // [2 x cap] per visibility item: closest hit on the light's own Model (k_trace<2>), layout of `hit`
     uint8_t  *vis;        // [2 x cap] 1 = blocked, per visibility item
     uint32_t *work;       // [b] = next queue index to hand out in k_trace<closest> of bounce b (persistent refill)
@@ -61,7 +64,7 @@ struct DPaths {
     uint32_t *spill_any;  // the same for k_trace<ANY>, which may run beside k_trace<closest> of the next bounce
     unsigned long long *stat;   // [0] closest rays [1] shadow rays [2] samples [3,4] extend node visits / tri tests [5,6] visibility ditto [7] guard
 };
-struct Params { uint32_t seed, width, height, max_bounces, rr_start, stack_entries, node_lanes, owner_lanes; };
+struct Params { uint32_t seed, width, height, max_bounces, rr_start, stack_entries, node_lanes, owner_lanes, gen; };
 
 __device__ __forceinline__ F3 xyz(float4 v) { return f3(v.x, v.y, v.z); }
 __device__ __forceinline__ float4 f4(F3 v, float w) { return make_float4(v.x, v.y, v.z, w); }
@@ -235,6 +238,9 @@ __global__ void __launch_bounds__(kExtBlock) k_trace(DScene S, DPaths P, Params 
     uint32_t chunk = (n / (8u * nwaves)) & ~63u; chunk = chunk < 64u ? 64u : (chunk > 1024u ? 1024u : chunk);
     const bool trickle = n < 64u * nwaves;
     if (trickle) { chunk = (n + nwaves - 1u) / nwaves; chunk = chunk < 4u ? 4u : chunk; }
+    if (MODE == 0 && blockIdx.x == 0 && lane == 0 && P.progress) {
+        __hip_atomic_store(&P.progress[bounce], ((unsigned long long)prm.gen << 32) | (unsigned long long)(n + 1u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
     if (blockIdx.x * chunk >= n) return;                         // nothing left for this wave even on the first deal
     const uint32_t ncache = (uint32_t)S.num_recs < kRecCache ? (uint32_t)S.num_recs : kRecCache;
     for (uint32_t i = lane; i < ncache * kRecStride; i += 64u) recl[i] = S.recs[i];
@@ -287,7 +293,11 @@ __global__ void __launch_bounds__(kExtBlock) k_trace(DScene S, DPaths P, Params 
                                 linst = (uint32_t)L.inst;
                                 const float4* R = (uint32_t)L.rec < ncache ? (const float4*)(recl + L.rec * kRecStride) : S.recs + (size_t)L.rec * kRecStride;
                                 float lz = 0.0f; bool front = false, hit;
-                                if (L.kind == MI355PT_OBJ_MODEL) {                // found by k_trace<2>
+                                if (S.plane_lights_only) {                        // scalar branch: the usual scene
+                                    const Ray lr = rec_ray(S, R, __float_as_uint(R[0].y), linst, wr, 1u);
+                                    F3 Pp;
+                                    hit = plane_hit(lr.p, lr.d, SIDE_BOTH, lz, front, Pp);
+                                } else if (L.kind == MI355PT_OBJ_MODEL) {         // found by k_trace<2>
                                     const uint4 v = P.lhit[slot];
                                     HitRec mh; mh.t = __uint_as_float(v.x); mh.inst = (int)v.y; mh.mesh = (int)v.z; mh.slot = v.w;
                                     hit = mh.inst >= 0; lz = mh.t;
@@ -920,6 +930,9 @@ struct mi355pt_render {
     hipStream_t side = nullptr;
     std::vector<hipEvent_t> fork, join;
     uint32_t overlap_from = 0;
+    unsigned long long* progress = nullptr;         // pinned host memory behind P.progress
+    uint32_t gen = 0; bool progress_timeout = false;
+    void* ctr = nullptr; size_t ctr_bytes = 0;      // the per-bounce counters of DPaths, one block
     std::vector<void*> allocs;
     float* mean = nullptr; uint32_t* cnt = nullptr; uint8_t* rgb8 = nullptr;
     uint32_t* own = nullptr; size_t n_own = 0;       // tile split: the pixels this renderer renders (nullptr = all)
@@ -935,6 +948,7 @@ struct mi355pt_render {
         for (hipEvent_t e : join) (void)hipEventDestroy(e);
         for (void* p : allocs) (void)hipFree(p);
         if (side) (void)hipStreamDestroy(side);
+        if (progress) (void)hipHostFree(progress);
         if (stream) (void)hipStreamDestroy(stream);
     }
 };
@@ -1208,6 +1222,8 @@ int mi355pt_scene_create(const mi355pt_scene_desc* desc, int32_t device, mi355pt
     d.models = sc->models.p; d.meshes = sc->meshes.p; d.bvh_nodes = sc->bvh_nodes.p; d.tris = sc->tris.p; d.faces = sc->faces.p;
     d.normals = sc->normals.p; d.uvw = sc->uvw.p; d.tangents = sc->tangents.p; d.bitangents = sc->bitangents.p;
     d.materials = sc->materials.p; d.texmaps = sc->texmaps.p; d.textures = sc->textures.p; d.lights = sc->lights.p; d.num_lights = (int)lights.size(); d.light_data = sc->light_data.p;
+    d.plane_lights_only = 1;
+    for (const DLight& L : lights) if (L.kind != MI355PT_OBJ_PLANE) d.plane_lights_only = 0;
     d.recs = sc->recs.p; d.num_recs = (int)(recs.size() / kRecStride);
     memcpy(d.env_color, desc->env_color, sizeof(d.env_color)); d.env_map = desc->env_map;
     for (int i = 0; i < 32; i++) {      // Texture::Sample tap offsets (scene.h:169-175), host libm like the reference
@@ -1288,8 +1304,14 @@ int mi355pt_render_create(mi355pt_scene* scene, const mi355pt_render_params* par
     HIP_TRY(dalloc((void**)&P.hit, cap * 16)); HIP_TRY(dalloc((void**)&P.sh, cap * 16 * kShVec));
     HIP_TRY(dalloc((void**)&P.queue[0], cap * 4)); HIP_TRY(dalloc((void**)&P.queue[1], cap * 4)); HIP_TRY(dalloc((void**)&P.squeue, cap * 4));
     const size_t nb = params->max_bounces + 2;
-    HIP_TRY(dalloc((void**)&P.counts, nb * 4)); HIP_TRY(dalloc((void**)&P.svcounts, nb * 8)); HIP_TRY(dalloc((void**)&P.work, nb * 4));
-    HIP_TRY(dalloc((void**)&P.vqueue, cap * 8)); HIP_TRY(dalloc((void**)&P.vwork, nb * 4)); HIP_TRY(dalloc((void**)&P.lwork, nb * 4));
+    {   // the per-bounce counters live in one block: one memset per run instead of five
+        const size_t nb8 = (nb + 1) & ~(size_t)1;
+        r->ctr_bytes = nb8 * 8 + 4 * nb8 * 4;
+        HIP_TRY(dalloc((void**)&r->ctr, r->ctr_bytes));
+        P.svcounts = (unsigned long long*)r->ctr;
+        P.counts = (uint32_t*)(P.svcounts + nb8); P.work = P.counts + nb8; P.vwork = P.work + nb8; P.lwork = P.vwork + nb8;
+    }
+    HIP_TRY(dalloc((void**)&P.vqueue, cap * 8));
     if (scene->model_lights) HIP_TRY(dalloc((void**)&P.lhit, cap * 2 * sizeof(uint4)));
     HIP_TRY(dalloc((void**)&P.vis, cap * 2));
     HIP_TRY(dalloc((void**)&P.stat, 16 * sizeof(unsigned long long)));
@@ -1347,6 +1369,11 @@ int mi355pt_render_create(mi355pt_scene* scene, const mi355pt_render_params* par
     if (const char* e = getenv("MI355PT_NODE_LANES")) r->node_lanes = (uint32_t)std::min(64, std::max(1, atoi(e)));
     if (const char* e = getenv("MI355PT_OWNER_LANES")) r->owner_lanes = (uint32_t)std::min(64, std::max(1, atoi(e)));
     r->count_work = getenv("MI355PT_COUNT_WORK") != nullptr;
+    if (!getenv("MI355PT_NO_EARLY_STOP")) {
+        HIP_TRY(hipHostMalloc((void**)&r->progress, nb * sizeof(unsigned long long), hipHostMallocMapped | hipHostMallocCoherent));
+        memset(r->progress, 0, nb * sizeof(unsigned long long));
+        HIP_TRY(hipHostGetDevicePointer((void**)&P.progress, r->progress, 0));
+    }
     if (getenv("MI355PT_VERBOSE")) fprintf(stderr, "mi355pt: tree depth %d, extend grid %d waves, LDS %zu B/wave\n", scene->max_depth, r->extend_grid, r->extend_lds);
     *out = r.release();
     return MI355PT_OK;
@@ -1393,13 +1420,8 @@ void drain_events(mi355pt_render* r) {
 int run_paths(mi355pt_render* r, uint32_t n, uint32_t jitter = 1, uint32_t only_extend = 0) {
     DPaths& P = r->P; const mi355pt_render_params& p = r->prm;
     const DScene& S = r->scene->d;
-    Params prm{p.seed, p.width, p.height, p.max_bounces, p.rr_start, r->stack_entries, r->node_lanes, r->owner_lanes};
-    const size_t nb = p.max_bounces + 2;
-    HIP_TRY(hipMemsetAsync(P.counts, 0, nb * 4, r->stream));
-    HIP_TRY(hipMemsetAsync(P.svcounts, 0, nb * 8, r->stream));
-    HIP_TRY(hipMemsetAsync(P.work, 0, nb * 4, r->stream));
-    HIP_TRY(hipMemsetAsync(P.vwork, 0, nb * 4, r->stream));
-    HIP_TRY(hipMemsetAsync(P.lwork, 0, nb * 4, r->stream));
+    Params prm{p.seed, p.width, p.height, p.max_bounces, p.rr_start, r->stack_entries, r->node_lanes, r->owner_lanes, ++r->gen};
+    HIP_TRY(hipMemsetAsync(r->ctr, 0, r->ctr_bytes, r->stream));     // counts, svcounts, work, vwork, lwork
     const int g = grid_for(r, n);
     const int ge = (int)std::max<size_t>(1, std::min<size_t>(((size_t)n + 63) / 64, (size_t)r->extend_grid));     // persistent: resident waves only
     const int gs = (int)std::max<size_t>(1, std::min<size_t>(((size_t)n + 63) / 64, (size_t)r->grid * 4));       // one wave per workgroup
@@ -1412,9 +1434,24 @@ int run_paths(mi355pt_render* r, uint32_t n, uint32_t jitter = 1, uint32_t only_
     };
     const uint32_t nbounce = only_extend ? 0u : p.max_bounces;
     bool pending = false;                                   // connect(b - 1) is still on the side stream
+    uint32_t last_fork = 0, last_join = 0;
     closest(0);
     for (uint32_t b = 0; b < nbounce; b++) {
-        if (pending) { HIP_TRY(hipStreamWaitEvent(r->stream, r->join[b - 1], 0)); pending = false; }
+        // Early stop: paths end by Russian roulette or by leaving the scene, and the launches of a bounce nobody reached
+        // still cost ~30 us each.  The host trails the GPU by two bounces from bounce 4 on (the queue stays 8 launches
+        // deep) and stops enqueuing once k_trace<0> has reported a bounce with no path.  A flag that does not arrive
+        // within 2 s (it always does) ends the waiting for good: every bounce is then enqueued as before.
+        if (r->progress && b >= 4 && !r->progress_timeout) {
+            volatile unsigned long long* flag = &r->progress[b - 2];
+            unsigned long long v = *flag;
+            if ((v >> 32) != prm.gen) {
+                const auto t0 = std::chrono::steady_clock::now();
+                for (uint32_t spin = 0; ((v = *flag) >> 32) != prm.gen; spin++)
+                    if ((spin & 1023u) == 1023u && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) { r->progress_timeout = true; break; }
+            }
+            if ((v >> 32) == prm.gen && (uint32_t)v == 1u) break;
+        }
+        if (pending) { HIP_TRY(hipStreamWaitEvent(r->stream, r->join[b - 1], 0)); pending = false; last_join = b - 1; }
         ev_begin(r, 1, r->stream);
         hipLaunchKernelGGL(k_shade, dim3(gs), dim3(kShadeBlock), 0, r->stream, S, r->cam, P, prm, b, n);
         ev_end(r, r->stream);
@@ -1436,9 +1473,11 @@ int run_paths(mi355pt_render* r, uint32_t n, uint32_t jitter = 1, uint32_t only_
         else hipLaunchKernelGGL((k_trace<1, false>), dim3(ge), dim3(kExtBlock), r->extend_lds, vs, S, P, prm, b, n);
         hipLaunchKernelGGL(k_connect, dim3(g), dim3(kBlock), 0, vs, S, P, b);
         ev_end(r, vs);
-        if (fork) { HIP_TRY(hipEventRecord(r->join[b], vs)); pending = true; }
+        if (fork) { HIP_TRY(hipEventRecord(r->join[b], vs)); pending = true; last_fork = b; }
         else if (b + 1 < nbounce) closest(b + 1);
     }
+    if (pending) HIP_TRY(hipStreamWaitEvent(r->stream, r->join[last_fork], 0));      // an early stop leaves connect(b) on the side stream
+    (void)last_join;
     if (!only_extend) hipLaunchKernelGGL(k_stats, dim3(1), dim3(64), 0, r->stream, P, n, p.max_bounces);
     HIP_TRY(hipGetLastError());
     return MI355PT_OK;

@@ -62,6 +62,7 @@ struct DScene {
     const DTexture* textures;
     const DLight*   lights;     int num_lights;
     const float*    light_data;
+    int             plane_lights_only;   // every light sits on a Plane: the kernels take the short analytic path (uniform branch)
     const float4*   recs;       int num_recs;
     float env_color[3];         int env_map;
     float filter_taps[64];           // (x, y) of the 32 elliptic filter taps, scene.h:169-181

@@ -477,7 +477,7 @@ PT_DEV F3 mat_eval(const MatCtx& m, F3 wi, F3 wo) {      // shadingNormal output
 PT_DEV void light_sample_point(const DScene& S, const DLight& L, Rng& rng, F3& sp, F3& sn) {
     const DNodeXf& n = S.nodes[L.node];
     F3 p, nn;
-    if (L.kind == MI355PT_OBJ_PLANE) {
+    if (S.plane_lights_only || L.kind == MI355PT_OBJ_PLANE) {
         const float x = rng.U() * 2.0f - 1.0f;
         const float y = rng.U() * 2.0f - 1.0f;
         p = f3(x, y, 0.0f); nn = f3(0.0f, 0.0f, 1.0f);
@@ -517,18 +517,18 @@ PT_DEV bool light_hit_point(const DScene& S, const Ray& wr, const DLight& L, con
     const DInst& li = S.insts[L.inst];
     lp = ln = f3(0, 0, 0);
     Surf h;
-    if (L.kind == MI355PT_OBJ_MODEL) {
+    float lz; bool front; F3 P;
+    if (S.plane_lights_only || L.kind == MI355PT_OBJ_PLANE) {
+        const Ray lr = to_inst(S, li, wr);
+        if (!plane_hit(lr.p, lr.d, SIDE_BOTH, lz, front, P)) return false;
+        h.N = front ? f3(0.0f, 0.0f, 1.0f) : -1.0f * f3(0.0f, 0.0f, 1.0f);
+    } else if (L.kind == MI355PT_OBJ_MODEL) {
         if (mh.inst < 0) return false;
         surf_from_hit(S, mh, wr, false, f3(0, 0, 0), f3(0, 0, 0), h);
         lp = h.p; ln = h.N;
         return h.front;
-    }
-    const Ray lr = to_inst(S, li, wr);
-    float lz; bool front; F3 P;
-    if (L.kind == MI355PT_OBJ_PLANE) {
-        if (!plane_hit(lr.p, lr.d, SIDE_BOTH, lz, front, P)) return false;
-        h.N = front ? f3(0.0f, 0.0f, 1.0f) : -1.0f * f3(0.0f, 0.0f, 1.0f);
     } else {
+        const Ray lr = to_inst(S, li, wr);
         if (!sphere_hit(lr.p, lr.d, SIDE_BOTH, lz, front, P)) return false;
         h.N = front ? P : -1.0f * P;                           // objects.cpp:685-790
     }
