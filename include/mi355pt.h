@@ -246,7 +246,10 @@ void mi355pt_render_destroy(mi355pt_render* render);
 
 /* Replaces: one pass of every RenderWorker over all pixels, `spp` times
  * (src/pathtracer.cpp:66-109): SamplePixel -> RenderPixel -> running mean -> RGB8.
- * Asynchronous on the renderer's stream; `mi355pt_render_sync` waits.              */
+ * Enqueues on the renderer's streams and returns before the GPU has finished: at the latest when the
+ * GPU is two bounces from the end of the step (the host stops enqueuing bounces once a bounce had no
+ * path left; MI355PT_NO_EARLY_STOP=1 in the environment makes the call fully asynchronous again).
+ * `mi355pt_render_sync` waits for completion.                                        */
 int mi355pt_render_step(mi355pt_render* render, uint32_t spp);
 int mi355pt_render_sync(mi355pt_render* render);
 
