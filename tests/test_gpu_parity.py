@@ -181,9 +181,10 @@ def test_traversal_schedule_same_results(built, name, monkeypatch):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", ["teapot_cornell", "textured_c2"])
-def test_stream_overlap_same_results(built, name):
+def test_stream_overlap_same_results(built, name, monkeypatch):
     """Visibility + connect of bounce b beside the closest-hit trace of bounce b + 1 (two streams, the default) against
-    every kernel back to back on one stream: same accumulators bit for bit, same ray counts."""
+    every kernel back to back on one stream, and the early stop of dead bounces against none: same accumulators bit
+    for bit, same ray counts."""
     s, orc, pt, w, h = built(name)
     out = []
     for from_bounce in (0, 2, 1 << 30):
@@ -196,6 +197,16 @@ def test_stream_overlap_same_results(built, name):
         st = p2.stats()
         out.append((mean.copy(), cnt.copy(), st["closest_rays"], st["shadow_rays"]))
         p2.close_render()
+    # ... and with every bounce enqueued up front instead of stopping at the first bounce without a path
+    monkeypatch.setenv("MI355PT_NO_EARLY_STOP", "1")
+    p2 = PathTracer(pt.dscene)
+    p2.Init(w, h)
+    p2.step(3)
+    p2.sync()
+    mean, cnt = p2.read_accum()
+    st = p2.stats()
+    out.append((mean.copy(), cnt.copy(), st["closest_rays"], st["shadow_rays"]))
+    p2.close_render()
     for o in out[1:]:
         assert np.array_equal(out[0][0].view(np.uint32), o[0].view(np.uint32))
         assert np.array_equal(out[0][1], o[1]) and out[0][2:] == o[2:]
@@ -340,3 +351,64 @@ def test_tile_split_matches_full_image(built):
         got += m; cgot += c
         p.close_render()
     assert np.array_equal(cgot, cfull) and np.array_equal(got.view(np.uint32), full.view(np.uint32))
+
+
+def _edge_scene(kind, w, h):
+    from pathtracer_amd import scene as sc, scenes
+    s = sc.Scene()
+    s.env_color = (0.4, 0.5, 0.6)
+    s.camera = sc.Camera((0, -20, 6), (0, 0, 3), (0, 0, 1), fov=40.0, width=w, height=h)
+    m = sc.MtlDisney("m", albedo=(0.7, 0.6, 0.5), roughness=0.6)
+    s.materials = [m]
+    if kind == "empty":                       # no object at all: every ray takes the environment term
+        return s
+    floor = s.rootNode.AppendChild(scenes._plane("Floor", m, 30.0))
+    if kind == "no_lights":                   # SampleLights with an empty light list
+        return s
+    s.rootNode.AppendChild(scenes._plane("QuadLight", m, 2.0, ((1, 0, 0), 180.0), (0, 0, 12), light=9.0))
+    if kind == "one_triangle":                # the smallest mesh: a root that is a leaf
+        tri = sc.Mesh(np.array([[-3, 0, 1], [3, 0, 1], [0, 0, 6]], dtype=np.float32), np.tile(np.array([[0, -1, 0]], dtype=np.float32), (3, 1)),
+                      np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0]], dtype=np.float32), np.array([[0, 1, 2]]))
+        s.rootNode.AppendChild(sc.Node("tri", sc.Model([tri]), m))
+    if kind == "degenerate":                  # zero-area and repeated-vertex faces beside a good one (NaN barycentrics)
+        v = np.array([[-3, 0, 1], [3, 0, 1], [0, 0, 6], [1, 0, 2], [1, 0, 2], [1, 0, 2], [-4, 1, 1], [4, 1, 1], [0, 1, 1]], dtype=np.float32)
+        me = sc.Mesh(v, np.tile(np.array([[0, -1, 0]], dtype=np.float32), (9, 1)), np.zeros((9, 3), dtype=np.float32),
+                     np.array([[0, 1, 2], [3, 4, 5], [6, 7, 8], [0, 0, 2]]))
+        s.rootNode.AppendChild(sc.Node("deg", sc.Model([me]), m))
+    return s
+
+
+@pytest.mark.parametrize("kind,w,h,bounces", [("empty", 37, 23, 30), ("no_lights", 37, 23, 30), ("one_triangle", 41, 29, 30),
+                                               ("degenerate", 41, 29, 30), ("one_triangle", 8, 8, 1), ("one_triangle", 1, 1, 2)])
+def test_edge_cases(kind, w, h, bounces):
+    """Empty scene, no lights, a one-triangle mesh, degenerate faces; ragged image sizes (not multiples of the 8x8 slot
+    blocks), a single pixel, a one-bounce path limit -- each against the oracle on every pixel."""
+    from oracle.binding import OracleScene
+    s = _edge_scene(kind, w, h)
+    pt = PathTracer(s, max_bounces=bounces)
+    pt.Init(w, h)
+    orc = OracleScene(s)
+    node, mesh, face, t = pt.trace_primary()
+    onode, omesh, oface, ot, _ = orc.trace_primary(pt.params, 0, 0, w, h)
+    assert np.array_equal(node, onode) and np.array_equal(mesh, omesh) and np.array_equal(face, oface)
+    assert np.array_equal(t.view(np.uint32), ot.view(np.uint32))
+    pixel = np.repeat(np.arange(w * h, dtype=np.uint32), 3)
+    sample = np.tile(np.arange(3, dtype=np.uint32), w * h)
+    lin, mp = pt.sample_radiance(pixel, sample)
+    assert np.isfinite(lin).all()
+    if kind == "no_lights":
+        # the reference (and so the oracle) computes rand() % 0 in SampleLights (render.h:89-94) and dies of SIGFPE on
+        # the first surface hit; the product skips the direct term instead: only the environment reaches the image
+        assert lin.max() > 0 and lin.max() < 50.0
+        pt.close_render()
+        return
+    olin, omp = orc.sample_radiance(pt.params, pixel, sample)
+    frac, _ = common.radiance_agreement(lin, olin)
+    assert frac >= 0.999, f"{kind}: {frac}"
+    pt.step(3)
+    pt.sync()
+    mean, cnt = pt.read_accum()
+    assert (cnt == 3).all()
+    want = omp.reshape(w * h, 3, 3).astype(np.float64).mean(axis=1)
+    assert common.rel_mse(mean, want) <= 1e-3
+    pt.close_render()
