@@ -906,13 +906,13 @@ struct mi355pt_scene {
     mi355pt_camera camera{};
     std::vector<ptb::MeshTree> trees;
     DevBuf<DNodeXf> nodes; DevBuf<DInst> insts; DevBuf<DModel> models; DevBuf<DMesh> meshes;
-    DevBuf<float4> bvh_nodes, tris, recs; DevBuf<uint32_t> faces; DevBuf<float> normals, uvw, tangents, bitangents;
+    DevBuf<float4> bvh_nodes, tris, attrs, recs; DevBuf<uint32_t> faces; DevBuf<float> normals, uvw, tangents, bitangents;
     DevBuf<mi355pt_material> materials; DevBuf<mi355pt_texmap> texmaps; DevBuf<DTexture> textures; DevBuf<DLight> lights; DevBuf<float> light_data;
     bool model_lights = false;        // some light sits on a Model: its own-object test is a BVH traversal (k_trace<2>)
     std::vector<void*> tex_data;
     uint64_t num_tris = 0, num_bvh_nodes = 0; int max_depth = 0;
     ~mi355pt_scene() {
-        nodes.release(); insts.release(); models.release(); meshes.release(); bvh_nodes.release(); tris.release(); recs.release(); faces.release();
+        nodes.release(); insts.release(); models.release(); meshes.release(); bvh_nodes.release(); tris.release(); attrs.release(); recs.release(); faces.release();
         normals.release(); uvw.release(); tangents.release(); bitangents.release(); materials.release(); texmaps.release();
         textures.release(); lights.release(); light_data.release();
         for (void* p : tex_data) (void)hipFree(p);
@@ -1095,7 +1095,7 @@ int mi355pt_scene_create(const mi355pt_scene_desc* desc, int32_t device, mi355pt
         memcpy(models[i].aabb, s.aabb, sizeof(s.aabb)); models[i].first_mesh = s.first_mesh; models[i].num_meshes = s.num_meshes;
     }
     std::vector<DMesh> meshes(desc->num_meshes);
-    std::vector<float4> bvh_nodes, tris;
+    std::vector<float4> bvh_nodes, tris, attrs;
     std::vector<uint32_t> faces; std::vector<float> normals, uvw, tangents, bitangents;
     sc->trees.resize(desc->num_meshes);
     const int threads = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
@@ -1134,6 +1134,7 @@ int mi355pt_scene_create(const mi355pt_scene_desc* desc, int32_t device, mi355pt
         }
         // triangle slots: v0 v1 v2 + position of the face in faces[]
         tris.resize(tris.size() + 3 * flat.slot_face.size());
+        attrs.resize(attrs.size() + 5 * flat.slot_face.size());
         for (size_t k = 0; k < flat.slot_face.size(); k++) {
             const uint32_t fpos = flat.slot_face[k];
             const uint32_t* f = s.faces + 4 * (size_t)fpos;
@@ -1142,6 +1143,13 @@ int mi355pt_scene_create(const mi355pt_scene_desc* desc, int32_t device, mi355pt
             t[0] = make_float4(a[0], a[1], a[2], b[0]); t[1] = make_float4(b[1], b[2], c[0], c[1]);
             float fid; memcpy(&fid, &fpos, 4);
             t[2] = make_float4(c[2], fid, 0.0f, 0.0f);
+            // shading attributes by slot too: the winning triangle's normals / uvw come with one load level instead of
+            // slot -> face -> vertex indices -> normals (three dependent round trips in k_shade)
+            float av[20] = {0};
+            for (int c3 = 0; c3 < 3; c3++)
+                for (int e = 0; e < 3; e++) { av[3 * c3 + e] = s.normals[3 * (size_t)f[c3] + e]; av[9 + 3 * c3 + e] = s.uvw[3 * (size_t)f[c3] + e]; }
+            float4* at = &attrs[5 * ((size_t)tri_base + k)];
+            for (int q = 0; q < 5; q++) at[q] = make_float4(av[4 * q], av[4 * q + 1], av[4 * q + 2], av[4 * q + 3]);
         }
         faces.insert(faces.end(), s.faces, s.faces + 4 * (size_t)s.num_faces);
         normals.insert(normals.end(), s.normals, s.normals + 3 * (size_t)s.num_vertices);
@@ -1213,13 +1221,13 @@ int mi355pt_scene_create(const mi355pt_scene_desc* desc, int32_t device, mi355pt
     }
     // ---- upload
     HIP_TRY(sc->nodes.upload(nodes)); HIP_TRY(sc->insts.upload(insts)); HIP_TRY(sc->models.upload(models)); HIP_TRY(sc->meshes.upload(meshes));
-    HIP_TRY(sc->bvh_nodes.upload(bvh_nodes)); HIP_TRY(sc->tris.upload(tris)); HIP_TRY(sc->faces.upload(faces));
+    HIP_TRY(sc->bvh_nodes.upload(bvh_nodes)); HIP_TRY(sc->tris.upload(tris)); HIP_TRY(sc->attrs.upload(attrs)); HIP_TRY(sc->faces.upload(faces));
     HIP_TRY(sc->normals.upload(normals)); HIP_TRY(sc->uvw.upload(uvw)); HIP_TRY(sc->tangents.upload(tangents)); HIP_TRY(sc->bitangents.upload(bitangents));
     HIP_TRY(sc->recs.upload(recs));
     HIP_TRY(sc->materials.upload(materials)); HIP_TRY(sc->texmaps.upload(texmaps)); HIP_TRY(sc->textures.upload(textures)); HIP_TRY(sc->lights.upload(lights)); HIP_TRY(sc->light_data.upload(light_data));
     DScene& d = sc->d;
     d.nodes = sc->nodes.p; d.num_nodes = (int)nodes.size(); d.insts = sc->insts.p; d.num_insts = (int)insts.size();
-    d.models = sc->models.p; d.meshes = sc->meshes.p; d.bvh_nodes = sc->bvh_nodes.p; d.tris = sc->tris.p; d.faces = sc->faces.p;
+    d.models = sc->models.p; d.meshes = sc->meshes.p; d.bvh_nodes = sc->bvh_nodes.p; d.tris = sc->tris.p; d.attrs = sc->attrs.p; d.faces = sc->faces.p;
     d.normals = sc->normals.p; d.uvw = sc->uvw.p; d.tangents = sc->tangents.p; d.bitangents = sc->bitangents.p;
     d.materials = sc->materials.p; d.texmaps = sc->texmaps.p; d.textures = sc->textures.p; d.lights = sc->lights.p; d.num_lights = (int)lights.size(); d.light_data = sc->light_data.p;
     d.plane_lights_only = 1;

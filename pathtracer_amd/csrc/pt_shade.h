@@ -21,8 +21,15 @@ PT_DEV F3 diff_tex(const Ray& dr, F3 pD, const Tri& T, F3 v01, F3 v02, F3 t0, F3
     const float b0 = a0 / a, b1 = a1 / a, b2 = a2 / a;
     return b0 * t0 + b1 * t1 + b2 * t2;
 }
-PT_DEV void surf_triangle(const DScene& S, const DMesh& M, uint32_t slot, const Ray& r, bool hasDiff, const Ray& rr, const Ray& tr, Surf& h) {
+// `needs_uv` / `with_tb`: the interpolated uvw (and its differentials) feed textures only, Tangent / Bitangent the
+// normal map only.  Normals and uvw are read from the per-slot attribute record, in the same load phase as the triangle.
+PT_DEV void surf_triangle(const DScene& S, const DMesh* M, uint32_t slot, const Ray& r, bool hasDiff, bool needs_uv, bool with_tb,
+                          const Ray& rr, const Ray& tr, Surf& h) {
     const Tri T = load_tri(S.tris, slot);
+    const float4* A = S.attrs + 5 * (size_t)slot;
+    const float4 A0 = A[0], A1 = A[1], A2 = A[2];
+    float4 A3 = make_float4(0, 0, 0, 0), A4 = make_float4(0, 0, 0, 0);
+    if (needs_uv) { A3 = A[3]; A4 = A[4]; }
     const F3 v01 = T.v1 - T.v0, v02 = T.v2 - T.v0;
     const F3 n = gcross(v01, v02);
     const float dn = gdot(r.d, n);
@@ -32,17 +39,14 @@ PT_DEV void surf_triangle(const DScene& S, const DMesh& M, uint32_t slot, const 
     float a0, a1, a2, a;
     tri_areas<true>(neg(r.d), v01, v02, T.v0, T.v1, T.v2, P, a0, a1, a2, a);
     const float b0 = a0 / a, b1 = a1 / a, b2 = a2 / a;
-    const uint32_t* f = S.faces + 4 * (size_t)(M.face_base + T.face);
-    const float* nb = S.normals + 3 * (size_t)M.vert_base;
-    const float* tb = S.uvw + 3 * (size_t)M.vert_base;
-    const F3 n0 = ld3(nb + 3 * (size_t)f[0]), n1 = ld3(nb + 3 * (size_t)f[1]), n2 = ld3(nb + 3 * (size_t)f[2]);
+    const F3 n0 = f3(A0.x, A0.y, A0.z), n1 = f3(A0.w, A1.x, A1.y), n2 = f3(A1.z, A1.w, A2.x);
     F3 normal = gnormalize(b0 * n0 + b1 * n1 + b2 * n2);
     const float ns = normal.x + normal.y + normal.z;
     if (isnan(ns) || isinf(ns)) normal = gnormalize(n);
-    const F3 t0 = ld3(tb + 3 * (size_t)f[0]), t1 = ld3(tb + 3 * (size_t)f[1]), t2 = ld3(tb + 3 * (size_t)f[2]);
+    const F3 t0 = f3(A2.y, A2.z, A2.w), t1 = f3(A3.x, A3.y, A3.z), t2 = f3(A3.w, A4.x, A4.y);
     h.T = f3(0, 0, 0); h.B = f3(0, 0, 0);
-    if (M.has_tangents) {
-        const size_t fi = (size_t)M.face_base + f[3];
+    if (with_tb && M->has_tangents) {
+        const size_t fi = (size_t)M->face_base + S.faces[4 * (size_t)(M->face_base + T.face) + 3];      // face.indices[3], model.h:330-335
         h.T = ld3(S.tangents + 3 * fi); h.B = ld3(S.bitangents + 3 * fi);
     }
     h.p = P; h.z = t; h.front = front;
@@ -122,7 +126,8 @@ PT_DEV void surf_from_hit(const DScene& S, const HitRec& hr, const Ray& wr, bool
     h.mtl = S.nodes[in.node].material;
     const mi355pt_material& mt = S.materials[h.mtl];
     const bool with_tb = mt.normal_map >= 0;
-    hasDiff = hasDiff && (with_tb || mt.albedo_map >= 0 || mt.roughness_map >= 0 || mt.metalness_map >= 0);
+    const bool needs_uv = with_tb || mt.albedo_map >= 0 || mt.roughness_map >= 0 || mt.metalness_map >= 0;
+    hasDiff = hasDiff && needs_uv;
     Ray r = wr, rr, tr;
     rr.p = wr.p; rr.d = rightDir; tr.p = wr.p; tr.d = topDir;
     for (int i = 0; i < in.chain_len; i++) {
@@ -132,7 +137,7 @@ PT_DEV void surf_from_hit(const DScene& S, const HitRec& hr, const Ray& wr, bool
     }
     if (in.kind == MI355PT_OBJ_PLANE) surf_plane(r, hasDiff, rr, tr, h);
     else if (in.kind == MI355PT_OBJ_SPHERE) surf_sphere(r, hasDiff, rr, tr, h);
-    else surf_triangle(S, S.meshes[S.models[in.model].first_mesh + hr.mesh], hr.slot, r, hasDiff, rr, tr, h);
+    else surf_triangle(S, with_tb ? &S.meshes[S.models[in.model].first_mesh + hr.mesh] : nullptr, hr.slot, r, hasDiff, needs_uv, with_tb, rr, tr, h);
     surf_to_world(S, in, h, with_tb);
 }
 
