@@ -23,11 +23,22 @@ PT_DEV F3 diff_tex(const Ray& dr, F3 pD, const Tri& T, F3 v01, F3 v02, F3 t0, F3
 }
 // `needs_uv` / `with_tb`: the interpolated uvw (and its differentials) feed textures only, Tangent / Bitangent the
 // normal map only.  Normals and uvw are read from the per-slot attribute record, in the same load phase as the triangle.
-PT_DEV void surf_triangle(const DScene& S, const DMesh* M, uint32_t slot, const Ray& r, bool hasDiff, bool needs_uv, bool with_tb,
+// The triangle and its normals are loaded by the caller before it walks the node chain (TriPre): they depend on the hit
+// record only, and the walk's own dependent loads would otherwise sit in front of them.
+struct TriPre { float4 t0, t1, t2, A0, A1, A2; };
+PT_DEV TriPre load_tri_pre(const DScene& S, uint32_t slot) {
+    TriPre p;
+    const float4* t = S.tris + 3 * (size_t)slot; const float4* A = S.attrs + 5 * (size_t)slot;
+    p.t0 = t[0]; p.t1 = t[1]; p.t2 = t[2]; p.A0 = A[0]; p.A1 = A[1]; p.A2 = A[2];
+    return p;
+}
+PT_DEV void surf_triangle(const DScene& S, const DMesh* M, uint32_t slot, const TriPre& pre, const Ray& r, bool hasDiff, bool needs_uv, bool with_tb,
                           const Ray& rr, const Ray& tr, Surf& h) {
-    const Tri T = load_tri(S.tris, slot);
+    Tri T;
+    T.v0 = f3(pre.t0.x, pre.t0.y, pre.t0.z); T.v1 = f3(pre.t0.w, pre.t1.x, pre.t1.y); T.v2 = f3(pre.t1.z, pre.t1.w, pre.t2.x);
+    T.face = __float_as_uint(pre.t2.y);
     const float4* A = S.attrs + 5 * (size_t)slot;
-    const float4 A0 = A[0], A1 = A[1], A2 = A[2];
+    const float4 A0 = pre.A0, A1 = pre.A1, A2 = pre.A2;
     float4 A3 = make_float4(0, 0, 0, 0), A4 = make_float4(0, 0, 0, 0);
     if (needs_uv) { A3 = A[3]; A4 = A[4]; }
     const F3 v01 = T.v1 - T.v0, v02 = T.v2 - T.v0;
@@ -121,6 +132,9 @@ PT_DEV void surf_to_world(const DScene& S, const DInst& in, Surf& h, bool with_t
 // Values nothing reads are not computed: the uv differentials feed the texture filter only, Tangent / Bitangent the
 // normal map only, so a hit on a material without maps skips them (what IS computed is computed as the reference does).
 PT_DEV void surf_from_hit(const DScene& S, const HitRec& hr, const Ray& wr, bool hasDiff, F3 rightDir, F3 topDir, Surf& h) {
+    TriPre pre;
+    pre.t0 = pre.t1 = pre.t2 = pre.A0 = pre.A1 = pre.A2 = make_float4(0, 0, 0, 0);
+    if (hr.mesh >= 0) pre = load_tri_pre(S, hr.slot);
     const DInst& in = S.insts[hr.inst];
     h.node = in.node;
     h.mtl = S.nodes[in.node].material;
@@ -137,7 +151,7 @@ PT_DEV void surf_from_hit(const DScene& S, const HitRec& hr, const Ray& wr, bool
     }
     if (in.kind == MI355PT_OBJ_PLANE) surf_plane(r, hasDiff, rr, tr, h);
     else if (in.kind == MI355PT_OBJ_SPHERE) surf_sphere(r, hasDiff, rr, tr, h);
-    else surf_triangle(S, with_tb ? &S.meshes[S.models[in.model].first_mesh + hr.mesh] : nullptr, hr.slot, r, hasDiff, needs_uv, with_tb, rr, tr, h);
+    else surf_triangle(S, with_tb ? &S.meshes[S.models[in.model].first_mesh + hr.mesh] : nullptr, hr.slot, pre, r, hasDiff, needs_uv, with_tb, rr, tr, h);
     surf_to_world(S, in, h, with_tb);
 }
 
