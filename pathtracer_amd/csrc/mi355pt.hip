@@ -591,7 +591,7 @@ __global__ void __launch_bounds__(kExtBlock) k_trace(DScene S, DPaths P, Params 
 // bounce 1 three rays in four leave the scene: without the gather the shading code ran at 26 % lanes.)
 constexpr int kShadeBlock = 64;
 #ifndef PT_SHADE_WAVES
-#define PT_SHADE_WAVES 1
+#define PT_SHADE_WAVES 2
 #endif
 __global__ void __launch_bounds__(kShadeBlock) __attribute__((amdgpu_waves_per_eu(PT_SHADE_WAVES, 8))) k_shade(DScene S, DCamera cam, DPaths P, Params prm, uint32_t bounce, uint32_t n0) {
     const uint32_t n = bounce == 0 ? n0 : P.counts[bounce];
