@@ -668,7 +668,7 @@ __global__ void __launch_bounds__(kShadeBlock) __attribute__((amdgpu_waves_per_e
             {
                 Surf h;
                 surf_from_hit(S, hr, r, hasDiff, rd, td, h);
-                const int hitLight = S.nodes[h.node].light;
+                const int hitLight = h.light;
                 if (hitLight >= 0 && bounce == 0) C = C + T * ld3(S.lights[hitLight].intensity);   // :137-141
                 F3 wo = -1.0f * r.d;
                 wo = wo / len(wo);
@@ -1023,7 +1023,7 @@ int mi355pt_scene_create(const mi355pt_scene_desc* desc, int32_t device, mi355pt
         if (s.object_kind != MI355PT_OBJ_PLANE && s.object_kind != MI355PT_OBJ_SPHERE && s.object_kind != MI355PT_OBJ_MODEL) return fail(MI355PT_ERR_UNSUPPORTED, "unknown object kind");
         if (s.material < 0 || (uint32_t)s.material >= desc->num_materials) return fail(MI355PT_ERR_INVALID, "object node without material");
         if (s.object_kind == MI355PT_OBJ_MODEL && (s.object_index < 0 || (uint32_t)s.object_index >= desc->num_models)) return fail(MI355PT_ERR_INVALID, "bad model index");
-        DInst in{}; in.node = (int)i; in.kind = s.object_kind; in.model = s.object_index;
+        DInst in{}; in.node = (int)i; in.kind = s.object_kind; in.model = s.object_index; in.material = s.material; in.light = s.light;
         std::vector<int> chain;
         for (int c = (int)i; c >= 0; c = desc->nodes[c].parent) chain.push_back(c);
         if (chain.size() > MI355PT_MAX_CHAIN) return fail(MI355PT_ERR_TOO_LARGE, "scene graph deeper than MI355PT_MAX_CHAIN");

@@ -15,6 +15,7 @@ struct DNodeXf {                 // one scene-graph node (reference Transformati
 };
 struct DInst {                   // one object-bearing node, in the reference's depth-first order
     int node, kind, model, chain_len;
+    int material, light, pad0, pad1;   // copies of the node's: one load level less on the way to the material
     int chain[MI355PT_MAX_CHAIN];    // node indices root -> node
 };
 struct DModel { float aabb[6]; int first_mesh, num_meshes; };

@@ -10,7 +10,7 @@ namespace ptd {
 struct Surf {
     float z;
     F3 p, N, T, B, uvw, du0, du1;
-    int node, mtl;
+    int node, mtl, light;
     bool front;
 };
 
@@ -137,7 +137,7 @@ PT_DEV void surf_from_hit(const DScene& S, const HitRec& hr, const Ray& wr, bool
     if (hr.mesh >= 0) pre = load_tri_pre(S, hr.slot);
     const DInst& in = S.insts[hr.inst];
     h.node = in.node;
-    h.mtl = S.nodes[in.node].material;
+    h.mtl = in.material; h.light = in.light;
     const mi355pt_material& mt = S.materials[h.mtl];
     const bool with_tb = mt.normal_map >= 0;
     const bool needs_uv = with_tb || mt.albedo_map >= 0 || mt.roughness_map >= 0 || mt.metalness_map >= 0;
@@ -450,7 +450,7 @@ PT_DEV void mat_prepare(const DScene& S, const Surf& h, MatCtx& m) {
         m.d.clearcoat = mt.clearcoat; m.d.clearcoatGloss = mt.clearcoat_gloss; m.d.sheen = mt.sheen; m.d.sheenTint = mt.sheen_tint;
         m.d.specular = mt.specular; m.d.specularTint = mt.specular_tint; m.d.subsurface = mt.subsurface;
         disney_finish(m.d);
-        const int li = S.nodes[h.node].light;
+        const int li = h.light;
         if (li >= 0) m.emission = ld3(S.lights[li].intensity);      // disneyMaterial.h:193-198
     } else {
         m.albedo = textured_color_srgb(S, mt.albedo, mt.albedo_map, h);
