@@ -106,7 +106,8 @@ __device__ __forceinline__ uint32_t xcd_block(uint32_t b, uint32_t nb) {
 // ---------------------------------------------------------------------- init
 __global__ void __launch_bounds__(kBlock) k_init(DPaths P, Params prm, uint32_t n, uint32_t pix_base, uint32_t npix_chunk,
                                                  const uint32_t* cnt, uint32_t sample_offset, uint32_t sample_stride,
-                                                 const uint32_t* list_pix, const uint32_t* list_smp, const uint32_t* own) {
+                                                 const uint32_t* list_pix, const uint32_t* list_smp, const uint32_t* own,
+                                                 DCamera cam, uint32_t with_rays) {
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         uint32_t pixel, sample;
         if (list_pix) { pixel = list_pix[i]; sample = list_smp[i]; }
@@ -118,6 +119,11 @@ __global__ void __launch_bounds__(kBlock) k_init(DPaths P, Params prm, uint32_t 
         }
         P.id[i] = make_uint4(pixel, sample, 2u, 0u);            // draws 0,1 = lens (utils.cpp:70,73)
         P.T[i] = make_float4(1.0f, 1.0f, 1.0f, 0.0f); P.C[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (with_rays) {                                        // k_raygen's work in the same pass (render_step, sample_radiance)
+            Ray r; F3 rd, td;
+            camera_rays(cam, prm.seed, pixel, sample, prm.width, true, r, rd, td);
+            P.ray[2 * (size_t)i] = f4(r.p, 0.0f); P.ray[2 * (size_t)i + 1] = f4(r.d, 0.0f);
+        }
     }
 }
 
@@ -1511,9 +1517,9 @@ int mi355pt_render_step(mi355pt_render* r, uint32_t spp) {
             const uint32_t n = np * ns;
             ev_begin(r, 3, r->stream);
             hipLaunchKernelGGL(k_init, dim3(grid_for(r, n)), dim3(kBlock), 0, r->stream, r->P, kprm,
-                               n, (uint32_t)pix_base, np, r->cnt, p.sample_offset, p.sample_stride, (const uint32_t*)nullptr, (const uint32_t*)nullptr, (const uint32_t*)r->own);
+                               n, (uint32_t)pix_base, np, r->cnt, p.sample_offset, p.sample_stride, (const uint32_t*)nullptr, (const uint32_t*)nullptr, (const uint32_t*)r->own, r->cam, 1u);
             ev_end(r, r->stream);
-            if (int rc = run_paths(r, n)) return rc;
+            if (int rc = run_paths(r, n, 2u)) return rc;
             ev_begin(r, 3, r->stream);
             hipLaunchKernelGGL(k_resolve, dim3(grid_for(r, np)), dim3(kBlock), 0, r->stream, r->P, r->mean, r->cnt, r->rgb8, (uint32_t)pix_base, np, ns, (const uint32_t*)r->own);
             ev_end(r, r->stream);
@@ -1631,8 +1637,8 @@ int mi355pt_sample_radiance(mi355pt_render* r, const uint32_t* pixel, const uint
     const mi355pt_render_params& p = r->prm;
     const Params kprm{p.seed, p.width, p.height, p.max_bounces, p.rr_start, r->stack_entries, r->node_lanes, r->owner_lanes};
     hipLaunchKernelGGL(k_init, dim3(grid_for(r, count)), dim3(kBlock), 0, r->stream, r->P, kprm,
-                       count, 0u, 1u, (const uint32_t*)r->cnt, 0u, 1u, (const uint32_t*)dp, (const uint32_t*)ds, (const uint32_t*)nullptr);
-    int rc = run_paths(r, count);
+                       count, 0u, 1u, (const uint32_t*)r->cnt, 0u, 1u, (const uint32_t*)dp, (const uint32_t*)ds, (const uint32_t*)nullptr, r->cam, 1u);
+    int rc = run_paths(r, count, 2u);
     hipLaunchKernelGGL(k_gather, dim3(grid_for(r, count)), dim3(kBlock), 0, r->stream, r->P, count, dl, dm);
     hipError_t e = hipStreamSynchronize(r->stream);
     if (e == hipSuccess && linear_rgb) e = hipMemcpy(linear_rgb, dl, (size_t)count * 12, hipMemcpyDeviceToHost);
