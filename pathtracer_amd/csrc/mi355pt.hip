@@ -349,9 +349,13 @@ __global__ void __launch_bounds__(kExtBlock) k_trace(DScene S, DPaths P, Params 
                     const float root_box[6] = {b3.x, b3.y, b3.z, b3.w, b4.x, b4.y};
                     const uint32_t root_ref = __float_as_uint(h1.z), root_cnt = __float_as_uint(h1.w);
                     float tn;
+                    // a box that is bit-identical to the one before it (a one-mesh model; a root bound equal to the mesh bound)
+                    // gives the same answer: the host marks those (rflags bits 1, 2) and the test is not repeated
                     const bool in_model = slab_straight(model_box, lr.p, linv, tn);          // Model::IntersectRay, model.cpp:212
-                    const bool in_mesh = slab_straight(mesh_box, lr.p, linv, tn);            // model.cpp:223-245
-                    const bool in_root = slab_straight(root_box, lr.p, linv, tn);
+                    bool in_mesh = in_model, in_root;
+                    if (!(rflags & 2u)) in_mesh = slab_straight(mesh_box, lr.p, linv, tn);   // model.cpp:223-245
+                    in_root = in_mesh;
+                    if (!(rflags & 4u)) in_root = slab_straight(root_box, lr.p, linv, tn);
                     if ((rflags & 1u) && !in_model) { rec = nexti; return false; }
                     bool go = in_mesh;
                     if (go && root_cnt == kInternal) { if (COUNT) wc.nodes++; go = in_root; }
@@ -1182,6 +1186,10 @@ int mi355pt_scene_create(const mi355pt_scene_desc* desc, int32_t device, mi355pt
             R[0] = make_float4(f_of((uint32_t)in.kind), f_of((uint32_t)in.chain_len), f_of(next), f_of(k == 0 ? 1u : 0u));
             if (in.kind == MI355PT_OBJ_MODEL) {
                 const DModel& mo = models[in.model]; const DMesh& M = meshes[mo.first_mesh + k];
+                uint32_t fl = k == 0 ? 1u : 0u;
+                if (memcmp(mo.aabb, M.aabb, sizeof(M.aabb)) == 0) fl |= 2u;             // same bits -> same slab result
+                if (memcmp(M.aabb, M.root_bound, sizeof(M.aabb)) == 0) fl |= 4u;
+                R[0].w = f_of(fl);
                 R[1] = make_float4(f_of((uint32_t)ii), f_of((uint32_t)k), f_of(M.root_ref), f_of(M.root_cnt));
                 R[2] = make_float4(mo.aabb[0], mo.aabb[1], mo.aabb[2], mo.aabb[3]);
                 R[3] = make_float4(mo.aabb[4], mo.aabb[5], M.aabb[0], M.aabb[1]);

@@ -40,7 +40,7 @@ struct DCamera {
 // then over a model's meshes), one record per Plane and one per (Model, mesh) pair, each holding everything the
 // per-ray set-up needs in one contiguous read: the node chain's transforms, the model / mesh / root bounds and the
 // BVH root.  Layout in float4 units (kRecStride per record):
-//   [0] kind, chain_len, first record of the NEXT object, flags (bit 0: first mesh of its model)    (uints)
+//   [0] kind, chain_len, first record of the NEXT object, flags (bit 0: first mesh of its model; bit 1: mesh box == model box, bit 2: root box == mesh box, bitwise)    (uints)
 //   [1] instance index, mesh index, root_ref, root_cnt                                               (uints)
 //   [2..4] model aabb (6), mesh aabb (6)      [5..6] root bound (6), 2 pad
 //   [7 + 3 l ..] level l of the chain, root first: itm (9), pos (3); levels >= kRecLevels are read from nodes[]
