@@ -300,9 +300,12 @@ __global__ void __launch_bounds__(kExtBlock) k_trace(DScene S, DPaths P, Params 
                                 const float4* R = (uint32_t)L.rec < ncache ? (const float4*)(recl + L.rec * kRecStride) : S.recs + (size_t)L.rec * kRecStride;
                                 float lz = 0.0f; bool front = false, hit;
                                 if (S.plane_lights_only) {                        // scalar branch: the usual scene
-                                    const Ray lr = rec_ray(S, R, __float_as_uint(R[0].y), linst, wr, 1u);
-                                    F3 Pp;
-                                    hit = plane_hit(lr.p, lr.d, SIDE_BOTH, lz, front, Pp);
+                                    if (slot & 1u) { hit = true; front = true; lz = sh[SHV_W2].w; }      // the MIS ray was tested by k_shade
+                                    else {
+                                        const Ray lr = rec_ray(S, R, __float_as_uint(R[0].y), linst, wr, 1u);
+                                        F3 Pp;
+                                        hit = plane_hit(lr.p, lr.d, SIDE_BOTH, lz, front, Pp);
+                                    }
                                 } else if (L.kind == MI355PT_OBJ_MODEL) {         // found by k_trace<2>
                                     const uint4 v = P.lhit[slot];
                                     HitRec mh; mh.t = __uint_as_float(v.x); mh.inst = (int)v.y; mh.mesh = (int)v.z; mh.slot = v.w;
@@ -614,6 +617,7 @@ __global__ void __launch_bounds__(kShadeBlock) __attribute__((amdgpu_waves_per_e
     constexpr uint32_t kOut = 256;
     __shared__ uint32_t ob_alive[kOut], ob_sq[kOut], ob_vq[2 * kOut];
     uint32_t na = 0, ns = 0, nv = 0;                              // wave-uniform fill counts
+    unsigned long long mis_blocked = 0;                           // LightVisTest calls decided here (per lane)
     auto flush = [&]() {
         __syncthreads();
         if (na) {
@@ -717,11 +721,22 @@ __global__ void __launch_bounds__(kShadeBlock) __attribute__((amdgpu_waves_per_e
                             A2 = NdotL2 * f2 * Le;
                             flags |= 2u;
                         }
+                        // LightVisTest's first sweep for the MIS ray, here rather than in k_trace<1> when every light is a Plane: most
+                        // BRDF-sampled directions miss the light's plane (or meet its back), the test is a few dozen instructions
+                        // next to this kernel's thousands, and an item that is blocked there is never queued, fetched or set up.
+                        // It still counts as one LightVisTest call.  A front hit hands its distance and LightComponent::Pdf(wi) on.
+                        float mis_lz = 0.0f, mis_pdf = 0.0f;
+                        if (S.plane_lights_only && (flags & 2u)) {
+                            Ray sr; sr.p = h.p + h.N * kBias; sr.d = wi2;
+                            F3 lp, ln; HitRec none; none.t = 0.0f; none.inst = -1; none.mesh = -1; none.slot = 0;
+                            if (!light_hit_point(S, sr, L, none, lp, ln, &mis_lz)) { flags &= ~2u; mis_blocked++; }
+                            else mis_pdf = light_pdf(L, h.p, lp, ln, len(lp - h.p));
+                        }
                         if (flags) {
                             const F3 so = h.p + h.N * kBias;
                             float4* sh = P.sh + (size_t)slot * kShVec;
-                            sh[SHV_O] = f4(so, dist); sh[SHV_W1] = f4(wi1, __int_as_float(li)); sh[SHV_W2] = f4(wi2, __int_as_float(li));
-                            sh[SHV_C1] = f4(c1, pdf2); sh[SHV_A2] = f4(A2, selectPdf); sh[SHV_HP] = f4(h.p, __uint_as_float(flags)); sh[SHV_TB] = f4(T, 0.0f);
+                            sh[SHV_O] = f4(so, dist); sh[SHV_W1] = f4(wi1, __int_as_float(li)); sh[SHV_W2] = f4(wi2, S.plane_lights_only ? mis_lz : __int_as_float(li));
+                            sh[SHV_C1] = f4(c1, pdf2); sh[SHV_A2] = f4(A2, selectPdf); sh[SHV_HP] = f4(h.p, __uint_as_float(flags)); sh[SHV_TB] = f4(T, mis_pdf);
                             shadow = true; vflags = flags;
                         }
                     }
@@ -761,6 +776,7 @@ __global__ void __launch_bounds__(kShadeBlock) __attribute__((amdgpu_waves_per_e
             if (na > kOut - 64u || ns > kOut - 64u || nv > 2u * kOut - 128u) flush();
         }
     }
+    wave_add64(mis_blocked, &P.stat[1]);
 }
 
 // ---------------------------------------------------------------------- connect (NEE shadow ray + MIS)
@@ -784,6 +800,10 @@ __global__ void __launch_bounds__(kBlock) k_connect(DScene S, DPaths P, uint32_t
             rays++;
             if (!P.vis[2 * (size_t)slot + 1]) {
                 // the light's hit point / normal of LightVisTest's first sweep (raytracer.cpp:67-97), for LightComponent::Pdf(wi)
+                // (scenes with Plane lights only: k_shade found both and left the pdf in the shadow record)
+                float lightPdf;
+                if (S.plane_lights_only) lightPdf = sh[SHV_TB].w;
+                else {
                 const DLight& L = S.lights[__float_as_int(sh[SHV_W1].w)];
                 Ray r; r.p = xyz(sh[SHV_O]); r.d = xyz(w2);
                 F3 lp, ln;
@@ -794,7 +814,8 @@ __global__ void __launch_bounds__(kBlock) k_connect(DScene S, DPaths P, uint32_t
                 }
                 light_hit_point(S, r, L, mh, lp, ln);
                 const F3 hp = xyz(hpf);
-                const float lightPdf = light_pdf(L, hp, lp, ln, len(lp - hp));
+                lightPdf = light_pdf(L, hp, lp, ln, len(lp - hp));
+                }
                 if (!(lightPdf <= 0.0f)) {
                     const float pb = c1.w;
                     const float w = (pb * pb) / (pb * pb + lightPdf * lightPdf);

@@ -532,11 +532,11 @@ PT_DEV float light_pdf(const DLight& L, F3 hitp, F3 sp, F3 sn, float distance) {
 // First sweep of LightVisTest (raytracer.cpp:67-97): the light's own object, both sides.  Returns true for a
 // front-side hit; lp / ln = the hit point / normal in world space.  (The second sweep, over every other object,
 // is k_trace<1> in mi355pt.hip.)  A Model's closest hit was found by k_trace<2> and is handed in as `mh`.
-PT_DEV bool light_hit_point(const DScene& S, const Ray& wr, const DLight& L, const HitRec& mh, F3& lp, F3& ln) {
+PT_DEV bool light_hit_point(const DScene& S, const Ray& wr, const DLight& L, const HitRec& mh, F3& lp, F3& ln, float* lz_out = nullptr) {
     const DInst& li = S.insts[L.inst];
     lp = ln = f3(0, 0, 0);
     Surf h;
-    float lz; bool front; F3 P;
+    float lz = 0.0f; bool front; F3 P;
     if (S.plane_lights_only || L.kind == MI355PT_OBJ_PLANE) {
         const Ray lr = to_inst(S, li, wr);
         if (!plane_hit(lr.p, lr.d, SIDE_BOTH, lz, front, P)) return false;
@@ -552,6 +552,7 @@ PT_DEV bool light_hit_point(const DScene& S, const Ray& wr, const DLight& L, con
         h.N = front ? P : -1.0f * P;                           // objects.cpp:685-790
     }
     h.p = P;
+    if (lz_out) *lz_out = lz;
     surf_to_world(S, li, h, false);
     lp = h.p; ln = h.N;
     return front;
