@@ -107,7 +107,7 @@ __device__ __forceinline__ uint32_t xcd_block(uint32_t b, uint32_t nb) {
 __global__ void __launch_bounds__(kBlock) k_init(DPaths P, Params prm, uint32_t n, uint32_t pix_base, uint32_t npix_chunk,
                                                  const uint32_t* cnt, uint32_t sample_offset, uint32_t sample_stride,
                                                  const uint32_t* list_pix, const uint32_t* list_smp, const uint32_t* own,
-                                                 DCamera cam, uint32_t with_rays, DScene S) {
+                                                 DCamera cam, uint32_t with_rays) {
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         uint32_t pixel, sample;
         if (list_pix) { pixel = list_pix[i]; sample = list_smp[i]; }
@@ -123,9 +123,6 @@ __global__ void __launch_bounds__(kBlock) k_init(DPaths P, Params prm, uint32_t 
             Ray r; F3 rd, td;
             camera_rays(cam, prm.seed, pixel, sample, prm.width, true, r, rd, td);
             P.ray[2 * (size_t)i] = f4(r.p, 0.0f); P.ray[2 * (size_t)i + 1] = f4(r.d, 0.0f);
-            float bt; int bi;
-            lead_hit(S, r, bt, bi);
-            store_hit(P, i, bt, bi, -1, 0u);
         }
     }
 }
@@ -134,24 +131,12 @@ __global__ void __launch_bounds__(kBlock) k_init(DPaths P, Params prm, uint32_t 
 // HaltonSampler::SamplePixel + GenCameraRayContext for every path of the chunk (sampler.cpp:15-32,
 // raytracer.cpp:272-316).  The main ray goes to P.ray so that k_extend reads every bounce the same way;
 // k_shade recomputes the two differential rays for the primary hit only.
-__global__ void __launch_bounds__(kBlock) k_raygen(DCamera cam, DPaths P, Params prm, uint32_t n, uint32_t jitter, DScene S) {
+__global__ void __launch_bounds__(kBlock) k_raygen(DCamera cam, DPaths P, Params prm, uint32_t n, uint32_t jitter) {
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         Ray r; F3 rd, td;
         const uint4 id = P.id[i];
         camera_rays(cam, prm.seed, id.x, id.y, prm.width, jitter != 0, r, rd, td);
         P.ray[2 * (size_t)i] = f4(r.p, 0.0f); P.ray[2 * (size_t)i + 1] = f4(r.d, 0.0f);
-        float bt; int bi;
-        lead_hit(S, r, bt, bi);
-        store_hit(P, i, bt, bi, -1, 0u);
-    }
-}
-// The same for rays a caller put into P.ray (mi355pt_trace_rays): every ray k_trace<0> walks starts from lead_hit's result.
-__global__ void __launch_bounds__(kBlock) k_lead(DPaths P, uint32_t n, DScene S) {
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        Ray r; r.p = xyz(P.ray[2 * (size_t)i]); r.d = xyz(P.ray[2 * (size_t)i + 1]);
-        float bt; int bi;
-        lead_hit(S, r, bt, bi);
-        store_hit(P, i, bt, bi, -1, 0u);
     }
 }
 
@@ -301,10 +286,6 @@ __global__ void __launch_bounds__(kExtBlock) k_trace(DScene S, DPaths P, Params 
                             rec = 0; state = LS_SETUP;
                             load_world(slot, wr);
                             if (!ANY) { best_t = kBig; best_inst = -1; best_mesh = -1; best_slot = 0; }
-                            if (MODE == 0 && S.num_lead > 0) {              // the ray's producer has been over the leading analytic records
-                                const uint4 h = P.hit[slot];
-                                best_t = __uint_as_float(h.x); best_inst = (int)h.y; rec = (uint32_t)S.num_lead;
-                            }
                             if (OWN) {
                                 const DLight& L = S.lights[__float_as_int(P.sh[(size_t)(slot >> 1) * kShVec + SHV_W1].w)];
                                 if (L.kind != MI355PT_OBJ_MODEL) state = LS_IDLE;       // nothing to do for this item
@@ -781,10 +762,6 @@ __global__ void __launch_bounds__(kShadeBlock) __attribute__((amdgpu_waves_per_e
                     P.T[slot] = f4(T, 0.0f);
                     P.ray[2 * (size_t)slot] = f4(np, 0.0f); P.ray[2 * (size_t)slot + 1] = f4(wi, 0.0f);
                     P.id[slot] = make_uint4(pixel, sample, rng.draw, 0u);
-                    Ray nr; nr.p = np; nr.d = wi;                    // the next ray against the leading analytic objects (lead_hit)
-                    float bt; int bi;
-                    lead_hit(S, nr, bt, bi);
-                    store_hit(P, slot, bt, bi, -1, 0u);
                 }
             }
         }
@@ -1251,9 +1228,6 @@ int mi355pt_scene_create(const mi355pt_scene_desc* desc, int32_t device, mi355pt
         }
     }
     inst_rec[insts.size()] = (int)(recs.size() / kRecStride);
-    int num_lead = 0;
-    while ((size_t)num_lead < insts.size() && insts[num_lead].kind != MI355PT_OBJ_MODEL) num_lead++;      // one record per analytic object
-    if (getenv("MI355PT_NO_LEAD")) num_lead = 0;
     for (auto& L : lights) { L.rec = L.inst >= 0 ? inst_rec[L.inst] : 0; L.rec_end = L.inst >= 0 ? inst_rec[L.inst + 1] : 0; }
     // ---- materials / textures
     std::vector<mi355pt_material> materials(desc->materials, desc->materials + desc->num_materials);
@@ -1290,7 +1264,7 @@ int mi355pt_scene_create(const mi355pt_scene_desc* desc, int32_t device, mi355pt
     d.nodes = sc->nodes.p; d.num_nodes = (int)nodes.size(); d.insts = sc->insts.p; d.num_insts = (int)insts.size();
     d.models = sc->models.p; d.meshes = sc->meshes.p; d.bvh_nodes = sc->bvh_nodes.p; d.tris = sc->tris.p; d.attrs = sc->attrs.p; d.faces = sc->faces.p;
     d.normals = sc->normals.p; d.uvw = sc->uvw.p; d.tangents = sc->tangents.p; d.bitangents = sc->bitangents.p;
-    d.materials = sc->materials.p; d.texmaps = sc->texmaps.p; d.textures = sc->textures.p; d.lights = sc->lights.p; d.num_lights = (int)lights.size(); d.light_data = sc->light_data.p; d.num_lead = num_lead;
+    d.materials = sc->materials.p; d.texmaps = sc->texmaps.p; d.textures = sc->textures.p; d.lights = sc->lights.p; d.num_lights = (int)lights.size(); d.light_data = sc->light_data.p;
     d.plane_lights_only = 1;
     for (const DLight& L : lights) if (L.kind != MI355PT_OBJ_PLANE) d.plane_lights_only = 0;
     d.recs = sc->recs.p; d.num_recs = (int)(recs.size() / kRecStride);
@@ -1486,7 +1460,7 @@ void drain_events(mi355pt_render* r) {
 }
 
 // The bounce loop for `n` initialised path slots.
-int run_paths(mi355pt_render* r, uint32_t n, uint32_t jitter = 1, uint32_t only_extend = 0, bool lead_done = false) {
+int run_paths(mi355pt_render* r, uint32_t n, uint32_t jitter = 1, uint32_t only_extend = 0) {
     DPaths& P = r->P; const mi355pt_render_params& p = r->prm;
     const DScene& S = r->scene->d;
     Params prm{p.seed, p.width, p.height, p.max_bounces, p.rr_start, r->stack_entries, r->node_lanes, r->owner_lanes, ++r->gen};
@@ -1494,8 +1468,7 @@ int run_paths(mi355pt_render* r, uint32_t n, uint32_t jitter = 1, uint32_t only_
     const int g = grid_for(r, n);
     const int ge = (int)std::max<size_t>(1, std::min<size_t>(((size_t)n + 63) / 64, (size_t)r->extend_grid));     // persistent: resident waves only
     const int gs = (int)std::max<size_t>(1, std::min<size_t>(((size_t)n + 63) / 64, (size_t)r->grid * 4));       // one wave per workgroup
-    if (jitter != 2) hipLaunchKernelGGL(k_raygen, dim3(g), dim3(kBlock), 0, r->stream, r->cam, P, prm, n, jitter, S);
-    else if (!lead_done) hipLaunchKernelGGL(k_lead, dim3(g), dim3(kBlock), 0, r->stream, P, n, S);
+    if (jitter != 2) hipLaunchKernelGGL(k_raygen, dim3(g), dim3(kBlock), 0, r->stream, r->cam, P, prm, n, jitter);
     auto closest = [&](uint32_t b) {
         ev_begin(r, 0, r->stream);
         if (r->count_work) hipLaunchKernelGGL((k_trace<0, true>), dim3(ge), dim3(kExtBlock), r->extend_lds, r->stream, S, P, prm, b, n);
@@ -1573,9 +1546,9 @@ int mi355pt_render_step(mi355pt_render* r, uint32_t spp) {
             const uint32_t n = np * ns;
             ev_begin(r, 3, r->stream);
             hipLaunchKernelGGL(k_init, dim3(grid_for(r, n)), dim3(kBlock), 0, r->stream, r->P, kprm,
-                               n, (uint32_t)pix_base, np, r->cnt, p.sample_offset, p.sample_stride, (const uint32_t*)nullptr, (const uint32_t*)nullptr, (const uint32_t*)r->own, r->cam, 1u, r->scene->d);
+                               n, (uint32_t)pix_base, np, r->cnt, p.sample_offset, p.sample_stride, (const uint32_t*)nullptr, (const uint32_t*)nullptr, (const uint32_t*)r->own, r->cam, 1u);
             ev_end(r, r->stream);
-            if (int rc = run_paths(r, n, 2u, 0u, true)) return rc;
+            if (int rc = run_paths(r, n, 2u)) return rc;
             ev_begin(r, 3, r->stream);
             hipLaunchKernelGGL(k_resolve, dim3(grid_for(r, np)), dim3(kBlock), 0, r->stream, r->P, r->mean, r->cnt, r->rgb8, (uint32_t)pix_base, np, ns, (const uint32_t*)r->own);
             ev_end(r, r->stream);
@@ -1693,8 +1666,8 @@ int mi355pt_sample_radiance(mi355pt_render* r, const uint32_t* pixel, const uint
     const mi355pt_render_params& p = r->prm;
     const Params kprm{p.seed, p.width, p.height, p.max_bounces, p.rr_start, r->stack_entries, r->node_lanes, r->owner_lanes};
     hipLaunchKernelGGL(k_init, dim3(grid_for(r, count)), dim3(kBlock), 0, r->stream, r->P, kprm,
-                       count, 0u, 1u, (const uint32_t*)r->cnt, 0u, 1u, (const uint32_t*)dp, (const uint32_t*)ds, (const uint32_t*)nullptr, r->cam, 1u, r->scene->d);
-    int rc = run_paths(r, count, 2u, 0u, true);
+                       count, 0u, 1u, (const uint32_t*)r->cnt, 0u, 1u, (const uint32_t*)dp, (const uint32_t*)ds, (const uint32_t*)nullptr, r->cam, 1u);
+    int rc = run_paths(r, count, 2u);
     hipLaunchKernelGGL(k_gather, dim3(grid_for(r, count)), dim3(kBlock), 0, r->stream, r->P, count, dl, dm);
     hipError_t e = hipStreamSynchronize(r->stream);
     if (e == hipSuccess && linear_rgb) e = hipMemcpy(linear_rgb, dl, (size_t)count * 12, hipMemcpyDeviceToHost);

@@ -399,24 +399,4 @@ PT_DEV bool sphere_hit(F3 o, F3 d, int side, float& t, bool& front, F3& P) {
     return true;
 }
 
-// Closest hit over the leading analytic walk records (Planes / Spheres that TraceNode visits before the first Model),
-// in their order, with the strict `<` of raytracer.cpp:208,238.  Whoever produces a ray (k_init, k_raygen, k_shade) runs
-// this with all lanes busy and leaves the result in the path's hit record; k_trace<0> starts its walk behind these
-// records with that result as the best so far -- same candidates, same order, same comparisons.
-PT_DEV void lead_hit(const DScene& S, Ray world, float& best_t, int& best_inst) {
-    best_t = kBig; best_inst = -1;
-    if (S.num_lead <= 0) return;
-    const Ray w1 = rec_ray(S, S.recs, 1u, 0u, world);            // level 0 of every chain is the root node
-    for (int rec = 0; rec < S.num_lead; rec++) {
-        const float4* R = S.recs + (size_t)rec * kRecStride;
-        const float4 h0 = R[0], h1 = R[1];
-        const uint32_t kind = __float_as_uint(h0.x), clen = __float_as_uint(h0.y), rii = __float_as_uint(h1.x);
-        const Ray lr = rec_ray(S, R, clen, rii, w1, 1u);
-        float t; bool front, hit; F3 Pp;
-        if (kind == MI355PT_OBJ_PLANE) hit = plane_hit(lr.p, lr.d, SIDE_BOTH, t, front, Pp);     // `kind` is wave-uniform: a scalar branch
-        else hit = sphere_hit(lr.p, lr.d, SIDE_BOTH, t, front, Pp);
-        if (hit && t < best_t) { best_t = t; best_inst = (int)rii; }
-    }
-}
-
 }  // namespace ptd

@@ -66,7 +66,6 @@ struct DScene {
     const float*    light_data;
     int             plane_lights_only;   // every light sits on a Plane: the kernels take the short analytic path (uniform branch)
     const float4*   recs;       int num_recs;
-    int             num_lead;            // walk records before the first Model's: analytic objects the ray's PRODUCER intersects (lead_hit)
     float env_color[3];         int env_map;
     float filter_taps[64];           // (x, y) of the 32 elliptic filter taps, scene.h:169-181
 };
