@@ -362,6 +362,10 @@ def _edge_scene(kind, w, h):
     s.materials = [m]
     if kind == "empty":                       # no object at all: every ray takes the environment term
         return s
+    if kind == "model_first":                 # a Model before any analytic object in TraceNode's order
+        tri = sc.Mesh(np.array([[-3, 0, 1], [3, 0, 1], [0, 0, 6]], dtype=np.float32), np.tile(np.array([[0, -1, 0]], dtype=np.float32), (3, 1)),
+                      np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0]], dtype=np.float32), np.array([[0, 1, 2]]))
+        s.rootNode.AppendChild(sc.Node("tri", sc.Model([tri]), m))
     floor = s.rootNode.AppendChild(scenes._plane("Floor", m, 30.0))
     if kind == "no_lights":                   # SampleLights with an empty light list
         return s
@@ -379,7 +383,8 @@ def _edge_scene(kind, w, h):
 
 
 @pytest.mark.parametrize("kind,w,h,bounces", [("empty", 37, 23, 30), ("no_lights", 37, 23, 30), ("one_triangle", 41, 29, 30),
-                                               ("degenerate", 41, 29, 30), ("one_triangle", 8, 8, 1), ("one_triangle", 1, 1, 2)])
+                                               ("degenerate", 41, 29, 30), ("one_triangle", 8, 8, 1), ("one_triangle", 1, 1, 2),
+                                               ("model_first", 41, 29, 30)])
 def test_edge_cases(kind, w, h, bounces):
     """Empty scene, no lights, a one-triangle mesh, degenerate faces; ragged image sizes (not multiples of the 8x8 slot
     blocks), a single pixel, a one-bounce path limit -- each against the oracle on every pixel."""
