@@ -12,7 +12,7 @@ from tests import common
 pytestmark = pytest.mark.gpu
 
 
-def random_scene(seed, w, h):
+def random_scene(seed, w, h, model_lights=False):
     rng = np.random.default_rng(seed)
     s = sc.Scene()
     s.env_color = tuple(float(x) for x in rng.uniform(0.0, 0.6, 3))
@@ -40,6 +40,15 @@ def random_scene(seed, w, h):
     tp = sc.Mesh((tp.vertices * np.float32(0.08)).astype(np.float32), tp.normals, tp.uvw, tp.faces[:, :3])
     quad = sc.Mesh(np.array([[-2, -2, 0], [2, -2, 0], [2, 2, 0], [-2, 2, 0]], dtype=np.float32), np.tile(np.array([[0, 0, 1]], dtype=np.float32), (4, 1)),
                    np.array([[0, 0, 0], [1, 0, 0], [1, 1, 0], [0, 1, 0]], dtype=np.float32), np.array([[0, 1, 2], [0, 2, 3]]))
+    if model_lights:                                             # a MeshBuilder-style Model light (and sometimes a zero-area one)
+        panel = sc.Model([quad, sc.Mesh((quad.vertices * np.float32(0.5) + np.float32([3, 0, 0.5])).astype(np.float32), quad.normals, quad.uvw, quad.faces[:, :3])],
+                         has_cdf=True)
+        ln = s.rootNode.AppendChild(sc.Node("panel", panel, mats[1], sc.LightComponent(tuple(float(x) for x in rng.uniform(3, 10, 3)))))
+        ln.Scale(float(rng.uniform(0.8, 1.6)), float(rng.uniform(0.8, 1.6)), 1.0); ln.Rotate((1, 0, 0), 180.0 + float(rng.uniform(-30, 30)))
+        ln.Translate((float(rng.uniform(-6, 6)), float(rng.uniform(-6, 6)), float(rng.uniform(8, 14))))
+        if rng.random() < 0.4:
+            b = s.rootNode.AppendChild(sc.Node("bulb", sc.Sphere(), mats[2], sc.LightComponent((4.0, 4.0, 4.0))))
+            b.Translate((float(rng.uniform(-6, 6)), float(rng.uniform(-6, 6)), 10.0))
     parent = s.rootNode
     for i in range(int(rng.integers(3, 9))):
         if rng.random() < 0.3:                                   # sometimes hang the next objects under a transformed group
@@ -66,11 +75,12 @@ def random_scene(seed, w, h):
     return s
 
 
-@pytest.mark.parametrize("seed", [101, 202, 303, 404, 505, 606])
-def test_random_scene(seed):
+@pytest.mark.parametrize("seed,model_lights", [(101, False), (202, False), (303, False), (404, False), (505, False), (606, False),
+                                               (707, True), (808, True), (909, True)])
+def test_random_scene(seed, model_lights):
     from oracle.binding import OracleScene
     w, h = 72, 54
-    s = random_scene(seed, w, h)
+    s = random_scene(seed, w, h, model_lights)
     pt = PathTracer(s)
     pt.Init(w, h)
     orc = OracleScene(s)
