@@ -225,6 +225,8 @@ def main():
                            "launches": int(launches), "avg_launch_ms": ext_ms / max(launches, 1),
                            "frac_exclusive": (xs["closest_rays"] * bytes_per_ray / (xs["extend_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS) if xs["extend_ms"] > 0 else None,
                            "avg_launch_ms_exclusive": xs["extend_ms"] / max(xs["extend_launches"], 1),
+                           # measured HBM rate of the kernel alone: PMC traffic per launch over the exclusive launch time
+                           "traffic_gbs_exclusive": (traffic / (xs["extend_ms"] / max(xs["extend_launches"], 1) * 1e-3) / 1e9) if traffic else None,
                            "avg_bytes_per_launch": closest * bytes_per_ray / max(launches, 1),
                            "shadow_n_node_per_ray": cs["shadow_node_visits"] / max(cs["shadow_rays"], 1),
                            "shadow_n_tri_per_ray": cs["shadow_tri_tests"] / max(cs["shadow_rays"], 1)}
