@@ -674,10 +674,19 @@ __global__ void __launch_bounds__(kShadeBlock) __attribute__((amdgpu_waves_per_e
             const uint32_t pixel = id.x, sample = id.y;
             Rng rng; rng.init(prm.seed, pixel, sample, id.z);
             Ray r; F3 rd = f3(0, 0, 0), td = f3(0, 0, 0);
-            const bool hasDiff = bounce == 0;
-            if (bounce == 0) camera_rays(cam, prm.seed, pixel, sample, prm.width, true, r, rd, td);
-            else { r.p = xyz(P.ray[2 * (size_t)slot]); r.d = xyz(P.ray[2 * (size_t)slot + 1]); }
+            r.p = xyz(P.ray[2 * (size_t)slot]); r.d = xyz(P.ray[2 * (size_t)slot + 1]);
             const HitRec hr = load_hit(P, slot);
+            // The differential rays of the primary hit feed the texture filter only: they are regenerated (with the main
+            // ray, whose bits equal the stored ones) just for hits on a material that has a map.
+            bool hasDiff = false;
+            if (bounce == 0) {
+                const mi355pt_material& m0 = S.materials[S.insts[hr.inst].material];
+                if (m0.albedo_map >= 0 || m0.roughness_map >= 0 || m0.metalness_map >= 0 || m0.normal_map >= 0) {
+                    Ray r0;
+                    camera_rays(cam, prm.seed, pixel, sample, prm.width, true, r0, rd, td);
+                    hasDiff = true;
+                }
+            }
             F3 T = xyz(P.T[slot]), C = xyz(P.C[slot]);
             {
                 Surf h;
