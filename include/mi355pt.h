@@ -301,8 +301,9 @@ int mi355pt_render_set_profiling(mi355pt_render* render, int enable_events, int 
  * back on one stream.  Results do not depend on it.  Takes effect at the next render_step. */
 int mi355pt_render_set_overlap(mi355pt_render* render, uint32_t from_bounce);
 
-/* The stream (hipStream_t) the renderer launches on, for callers that time kernels
- * with their own HIP events.                                                        */
+/* The renderer's main stream (hipStream_t): every step begins and ends on it (the second stream's
+ * work is joined into it before the step's last kernel), so an event recorded on it after
+ * mi355pt_render_step, or a wait on it, orders against the whole step.                          */
 void* mi355pt_render_stream(mi355pt_render* render);
 
 #ifdef __cplusplus
