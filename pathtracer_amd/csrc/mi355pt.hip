@@ -57,6 +57,7 @@ struct DPaths {
     uint32_t *lwork;      // [b] = the same for k_trace<2> (scenes with a light on a Model only)
     unsigned long long *progress;   // host-visible (pinned): [b] = (run generation << 32) | (paths queued for bounce b) + 1, written
                                     // when k_trace<0>(b) starts; the host stops enqueuing bounces once a bounce had no path left
+    float4 *prep;         // [4 x cap] per path slot: the ray as k_prepare left it at its first mesh (see k_prepare)
     uint4 *lhit;          // [2 x cap] per visibility item: closest hit on the light's own Model (k_trace<2>), layout of `hit`
     uint8_t  *vis;        // [2 x cap] 1 = blocked, per visibility item
     uint32_t *work;       // [b] = next queue index to hand out in k_trace<closest> of bounce b (persistent refill)
@@ -64,7 +65,7 @@ struct DPaths {
     uint32_t *spill_any;  // the same for k_trace<ANY>, which may run beside k_trace<closest> of the next bounce
     unsigned long long *stat;   // [0] closest rays [1] shadow rays [2] samples [3,4] extend node visits / tri tests [5,6] visibility ditto [7] guard
 };
-struct Params { uint32_t seed, width, height, max_bounces, rr_start, stack_entries, node_lanes, owner_lanes, gen; };
+struct Params { uint32_t seed, width, height, max_bounces, rr_start, stack_entries, node_lanes, owner_lanes, gen, use_prep; };
 
 __device__ __forceinline__ F3 xyz(float4 v) { return f3(v.x, v.y, v.z); }
 __device__ __forceinline__ float4 f4(F3 v, float w) { return make_float4(v.x, v.y, v.z, w); }
@@ -185,6 +186,67 @@ __device__ __forceinline__ unsigned long long hit_key(float t, uint32_t slot) {
 }
 __device__ __forceinline__ float key_dist(unsigned long long k) { return (k & 1ull) ? -0.0f : __uint_as_float((uint32_t)(k >> 32)); }
 
+// ---------------------------------------------------------------------- set-up pre-pass
+// TraceNode's walk over the objects (raytracer.cpp:189-258) for every ray of a bounce's queue, up to the first mesh the
+// ray has to traverse -- the same record-by-record code as k_trace<0>'s set-up, but as a streaming pass with all 64 lanes
+// busy (in the traversal kernel only the lanes that just finished a ray take part, about 24 of 64).  It leaves a 64-B
+// "prepared ray" per path slot: mesh-space origin | best t so far, direction | best object, 1/d | record reached,
+// root entry.  A ray with no mesh in its way is finished here (its hit record is written, record = 0xFFFFFFFF).
+// k_trace<0> (Params::use_prep) picks the ray up at that mesh; the walk behind it stays in the traversal kernel.
+__global__ void __launch_bounds__(kBlock) k_prepare(DScene S, DPaths P, uint32_t bounce, uint32_t n0) {
+    const uint32_t n = bounce == 0 ? n0 : P.counts[bounce];
+    const uint32_t* q = bounce == 0 ? nullptr : P.queue[bounce & 1];
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const uint32_t slot = q ? q[i] : i;
+        Ray wr; wr.p = xyz(P.ray[2 * (size_t)slot]); wr.d = xyz(P.ray[2 * (size_t)slot + 1]);
+        if (S.num_recs > 0) wr = rec_ray(S, S.recs, 1u, 0u, wr);
+        float best_t = kBig; int best_inst = -1;
+        uint32_t rec = 0;
+        bool found = false;
+        F3 o = f3(0, 0, 0), d = f3(0, 0, 0), inv = f3(0, 0, 0); uint32_t root_ref = 0, root_cnt = 0;
+        while (rec < (uint32_t)S.num_recs) {
+            const float4* R = S.recs + (size_t)rec * kRecStride;
+            const float4 h0 = R[0], h1 = R[1];
+            const uint32_t kind = __float_as_uint(h0.x), clen = __float_as_uint(h0.y), nexti = __float_as_uint(h0.z), rflags = __float_as_uint(h0.w);
+            const uint32_t rii = __float_as_uint(h1.x);
+            const Ray lr = rec_ray(S, R, clen, rii, wr, 1u);
+            if (kind != MI355PT_OBJ_MODEL) {
+                float t; bool front; F3 Pp;
+                const bool hit = kind == MI355PT_OBJ_PLANE ? plane_hit(lr.p, lr.d, SIDE_BOTH, t, front, Pp) : sphere_hit(lr.p, lr.d, SIDE_BOTH, t, front, Pp);
+                if (hit && t < best_t) { best_t = t; best_inst = (int)rii; }
+                rec = nexti;
+                continue;
+            }
+            const F3 linv = f3(1.0f, 1.0f, 1.0f) / lr.d;
+            const float4 b0 = R[2], b1 = R[3], b2 = R[4], b3 = R[5], b4 = R[6];
+            const float model_box[6] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y}, mesh_box[6] = {b1.z, b1.w, b2.x, b2.y, b2.z, b2.w};
+            const float root_box[6] = {b3.x, b3.y, b3.z, b3.w, b4.x, b4.y};
+            float tn;
+            const bool in_model = slab_straight(model_box, lr.p, linv, tn);
+            bool in_mesh = in_model, in_root;
+            if (!(rflags & 2u)) in_mesh = slab_straight(mesh_box, lr.p, linv, tn);
+            in_root = in_mesh;
+            if (!(rflags & 4u)) in_root = slab_straight(root_box, lr.p, linv, tn);
+            if ((rflags & 1u) && !in_model) { rec = nexti; continue; }
+            const uint32_t rc = __float_as_uint(h1.w);
+            bool go = in_mesh;
+            if (go && rc == kInternal) go = in_root;
+            if (go && rc == 0u) go = false;
+            if (!go) { rec++; continue; }
+            found = true; o = lr.p; d = lr.d; inv = linv; root_ref = __float_as_uint(h1.z); root_cnt = rc;
+            break;
+        }
+        float4* A = P.prep + 4 * (size_t)slot;
+        if (found) {
+            A[0] = make_float4(o.x, o.y, o.z, best_t); A[1] = make_float4(d.x, d.y, d.z, __int_as_float(best_inst));
+            A[2] = make_float4(inv.x, inv.y, inv.z, __uint_as_float(rec)); A[3] = make_float4(__uint_as_float(root_ref), __uint_as_float(root_cnt), 0.0f, 0.0f);
+        } else {
+            store_hit(P, slot, best_t, best_inst, -1, 0u);
+            A[2] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(0xFFFFFFFFu));
+        }
+    }
+}
+
 //
 // MODE 0 (ANY = false): closest hit of the rays in P.ray (k_extend).  MODE 1 (ANY = true): LightVisTest's sweep over
 // the objects that are not the light (raytracer.cpp:99-152) for the visibility items queued by k_shade: an item is
@@ -268,6 +330,7 @@ __global__ void __launch_bounds__(kExtBlock) k_trace(DScene S, DPaths P, Params 
             if (state == LS_SETUP) load_world(slot, wr);
             bool claimed = false;
             for (;;) {
+                bool prepped = false; F3 p_o = f3(0, 0, 0), p_d = f3(0, 0, 0), p_inv = f3(0, 0, 0); uint32_t p_ref = 0, p_cnt = 0;
                 if (state == LS_IDLE && lane >= prm.owner_lanes) state = LS_DONE;     // test knob: these lanes only ever steal
                 const unsigned long long need = __ballot(state == LS_IDLE);
                 if (need) {
@@ -284,8 +347,21 @@ __global__ void __launch_bounds__(kExtBlock) k_trace(DScene S, DPaths P, Params 
                         if (idx < pool_end) {
                             slot = q ? q[idx] : idx;
                             rec = 0; state = LS_SETUP;
+                            if (MODE == 0 && prm.use_prep) {                  // k_prepare has walked this ray up to its first mesh
+                                const float4* A = P.prep + 4 * (size_t)slot;
+                                const float4 a0 = A[0], a1 = A[1], a2 = A[2], a3 = A[3];
+                                rec = __float_as_uint(a2.w);
+                                if (rec == 0xFFFFFFFFu) state = LS_IDLE;      // no mesh in its way: the hit is already stored
+                                else {
+                                    prepped = true;
+                                    p_o = f3(a0.x, a0.y, a0.z); p_d = f3(a1.x, a1.y, a1.z); p_inv = f3(a2.x, a2.y, a2.z);
+                                    p_ref = __float_as_uint(a3.x); p_cnt = __float_as_uint(a3.y);
+                                    best_t = a0.w; best_inst = __float_as_int(a1.w); best_mesh = -1; best_slot = 0;
+                                }
+                            } else {
                             load_world(slot, wr);
                             if (!ANY) { best_t = kBig; best_inst = -1; best_mesh = -1; best_slot = 0; }
+                            }
                             if (OWN) {
                                 const DLight& L = S.lights[__float_as_int(P.sh[(size_t)(slot >> 1) * kShVec + SHV_W1].w)];
                                 if (L.kind != MI355PT_OBJ_MODEL) state = LS_IDLE;       // nothing to do for this item
@@ -329,6 +405,22 @@ __global__ void __launch_bounds__(kExtBlock) k_trace(DScene S, DPaths P, Params 
                 // ---- TraceNode's / LightVisTest's walk over the objects (earlier object wins ties, raytracer.cpp:208,238),
                 // record by record, until a mesh has to be traversed or the ray is finished
                 uint32_t root_leaf = 0;                               // leaf item to enqueue when a mesh's root is a leaf
+                // starts the traversal of a mesh for this lane's ray (mesh-space origin / direction / 1/d, root entry)
+                auto enter_mesh = [&](F3 lp, F3 ld, F3 linv, uint32_t root_ref, uint32_t root_cnt) {
+                    // the mesh starts from the best so far with slot key 0: an equal-t candidate of a later
+                    // mesh / object loses (model.cpp:237), only a strictly closer one replaces it
+                    rayl[2 * lane] = make_float4(lp.x, lp.y, lp.z, bound);
+                    rayl[2 * lane + 1] = make_float4(ld.x, ld.y, ld.z, 0.0f);
+                    keyl[lane] = ANY ? 0ull : hit_key(best_t, 0u) & ~1ull;       // any: 1 = blocked
+                    owner = lane; sb = 0; lo = 0;
+                    if (root_cnt >= kChain) {
+                        o = lp; inv = linv; pabs = prune_abs(lp); bt = ANY ? bound : best_t;
+                        PT_STK(0) = root_ref; sp = 1; nwork[lane] = 1; state = LS_TRAV;
+                    } else {
+                        root_leaf = kLeafFlag | ((root_cnt - 1u) << 27) | root_ref;
+                        sp = 0; nwork[lane] = 0; state = LS_WAIT;
+                    }
+                };
                 // processes record `rec`; returns true when the lane has left the object walk (traversal started, or ray finished)
                 auto walk_rec = [&](auto R) -> bool {
                     const float4 h0 = R[0], h1 = R[1];
@@ -364,22 +456,11 @@ __global__ void __launch_bounds__(kExtBlock) k_trace(DScene S, DPaths P, Params 
                     if (go && root_cnt == kInternal) { if (COUNT) wc.nodes++; go = in_root; }
                     if (go && root_cnt == 0u) go = false;
                     if (!go) { rec++; return false; }
-                    // the mesh starts from the best so far with slot key 0: an equal-t candidate of a later
-                    // mesh / object loses (model.cpp:237), only a strictly closer one replaces it
-                    rayl[2 * lane] = make_float4(lr.p.x, lr.p.y, lr.p.z, bound);
-                    rayl[2 * lane + 1] = make_float4(lr.d.x, lr.d.y, lr.d.z, 0.0f);
-                    keyl[lane] = ANY ? 0ull : hit_key(best_t, 0u) & ~1ull;       // any: 1 = blocked
-                    owner = lane; sb = 0; lo = 0;
-                    if (root_cnt >= kChain) {
-                        o = lr.p; inv = linv; pabs = prune_abs(lr.p); bt = ANY ? bound : best_t;
-                        PT_STK(0) = root_ref; sp = 1; nwork[lane] = 1; state = LS_TRAV;
-                    } else {
-                        root_leaf = kLeafFlag | ((root_cnt - 1u) << 27) | root_ref;
-                        sp = 0; nwork[lane] = 0; state = LS_WAIT;
-                    }
+                    enter_mesh(lr.p, lr.d, linv, root_ref, root_cnt);
                     return true;
                 };
-                if (state == LS_SETUP) {
+                if (MODE == 0 && prepped) enter_mesh(p_o, p_d, p_inv, p_ref, p_cnt);
+                else if (state == LS_SETUP) {
                     for (;;) {
                         if (rec >= (OWN ? rec_end : (uint32_t)S.num_recs)) {
                             if (ANY) P.vis[slot] = 0;
@@ -972,6 +1053,7 @@ struct mi355pt_render {
     uint32_t overlap_from = 0;
     unsigned long long* progress = nullptr;         // pinned host memory behind P.progress
     uint32_t gen = 0; bool progress_timeout = false;
+    uint32_t prep_bounces = 0;                      // bounces whose closest-hit trace is fed by k_prepare (the large ones)
     void* ctr = nullptr; size_t ctr_bytes = 0;      // the per-bounce counters of DPaths, one block
     std::vector<void*> allocs;
     float* mean = nullptr; uint32_t* cnt = nullptr; uint8_t* rgb8 = nullptr;
@@ -1365,6 +1447,9 @@ int mi355pt_render_create(mi355pt_scene* scene, const mi355pt_render_params* par
     }
     HIP_TRY(dalloc((void**)&P.vqueue, cap * 8));
     if (scene->model_lights) HIP_TRY(dalloc((void**)&P.lhit, cap * 2 * sizeof(uint4)));
+    r->prep_bounces = params->rr_start + 2;         // the bounces before Russian roulette has thinned the queues (C4: 5 beats 2, 8 and 30)
+    if (const char* e = getenv("MI355PT_PREP_BOUNCES")) r->prep_bounces = (uint32_t)std::max(0, atoi(e));
+    if (r->prep_bounces) HIP_TRY(dalloc((void**)&P.prep, cap * 4 * sizeof(float4)));
     HIP_TRY(dalloc((void**)&P.vis, cap * 2));
     HIP_TRY(dalloc((void**)&P.stat, 16 * sizeof(unsigned long long)));
     HIP_TRY(hipMemsetAsync(P.stat, 0, 16 * sizeof(unsigned long long), r->stream));
@@ -1479,9 +1564,12 @@ int run_paths(mi355pt_render* r, uint32_t n, uint32_t jitter = 1, uint32_t only_
     const int gs = (int)std::max<size_t>(1, std::min<size_t>(((size_t)n + 63) / 64, (size_t)r->grid * 4));       // one wave per workgroup
     if (jitter != 2) hipLaunchKernelGGL(k_raygen, dim3(g), dim3(kBlock), 0, r->stream, r->cam, P, prm, n, jitter);
     auto closest = [&](uint32_t b) {
+        Params pb = prm;
+        pb.use_prep = (!r->count_work && b < r->prep_bounces) ? 1u : 0u;      // counting builds count the walk's root-bound visits in the kernel
+        if (pb.use_prep) hipLaunchKernelGGL(k_prepare, dim3(g), dim3(kBlock), 0, r->stream, S, P, b, n);
         ev_begin(r, 0, r->stream);
-        if (r->count_work) hipLaunchKernelGGL((k_trace<0, true>), dim3(ge), dim3(kExtBlock), r->extend_lds, r->stream, S, P, prm, b, n);
-        else hipLaunchKernelGGL((k_trace<0, false>), dim3(ge), dim3(kExtBlock), r->extend_lds, r->stream, S, P, prm, b, n);
+        if (r->count_work) hipLaunchKernelGGL((k_trace<0, true>), dim3(ge), dim3(kExtBlock), r->extend_lds, r->stream, S, P, pb, b, n);
+        else hipLaunchKernelGGL((k_trace<0, false>), dim3(ge), dim3(kExtBlock), r->extend_lds, r->stream, S, P, pb, b, n);
         ev_end(r, r->stream);
     };
     const uint32_t nbounce = only_extend ? 0u : p.max_bounces;
