@@ -1054,6 +1054,7 @@ struct mi355pt_render {
     unsigned long long* progress = nullptr;         // pinned host memory behind P.progress
     uint32_t gen = 0; bool progress_timeout = false;
     uint32_t prep_bounces = 0;                      // bounces whose closest-hit trace is fed by k_prepare (the large ones)
+    uint32_t prep_min_paths = 1u << 22;             // ... in runs of at least this many paths (MI355PT_PREP_MIN_PATHS)
     void* ctr = nullptr; size_t ctr_bytes = 0;      // the per-bounce counters of DPaths, one block
     std::vector<void*> allocs;
     float* mean = nullptr; uint32_t* cnt = nullptr; uint8_t* rgb8 = nullptr;
@@ -1449,6 +1450,7 @@ int mi355pt_render_create(mi355pt_scene* scene, const mi355pt_render_params* par
     if (scene->model_lights) HIP_TRY(dalloc((void**)&P.lhit, cap * 2 * sizeof(uint4)));
     r->prep_bounces = params->rr_start + 2;         // the bounces before Russian roulette has thinned the queues (C4: 5 beats 2, 8 and 30)
     if (const char* e = getenv("MI355PT_PREP_BOUNCES")) r->prep_bounces = (uint32_t)std::max(0, atoi(e));
+    if (const char* e = getenv("MI355PT_PREP_MIN_PATHS")) r->prep_min_paths = (uint32_t)std::max(0, atoi(e));
     if (r->prep_bounces) HIP_TRY(dalloc((void**)&P.prep, cap * 4 * sizeof(float4)));
     HIP_TRY(dalloc((void**)&P.vis, cap * 2));
     HIP_TRY(dalloc((void**)&P.stat, 16 * sizeof(unsigned long long)));
@@ -1565,7 +1567,10 @@ int run_paths(mi355pt_render* r, uint32_t n, uint32_t jitter = 1, uint32_t only_
     if (jitter != 2) hipLaunchKernelGGL(k_raygen, dim3(g), dim3(kBlock), 0, r->stream, r->cam, P, prm, n, jitter);
     auto closest = [&](uint32_t b) {
         Params pb = prm;
-        pb.use_prep = (!r->count_work && b < r->prep_bounces) ? 1u : 0u;      // counting builds count the walk's root-bound visits in the kernel
+        // The pre-pass pays where most rays go on to traverse a mesh and the launch is large (C4: -0.6 ms); it costs a launch
+        // and 96 B per ray, which lost 4-13 % on the all-analytic C1 / C3 and on the 2 M-path C2.  Counting builds count
+        // the walk's root-bound visits in the kernel.
+        pb.use_prep = (!r->count_work && b < r->prep_bounces && r->scene->num_tris > 0 && n >= r->prep_min_paths) ? 1u : 0u;
         if (pb.use_prep) hipLaunchKernelGGL(k_prepare, dim3(g), dim3(kBlock), 0, r->stream, S, P, b, n);
         ev_begin(r, 0, r->stream);
         if (r->count_work) hipLaunchKernelGGL((k_trace<0, true>), dim3(ge), dim3(kExtBlock), r->extend_lds, r->stream, S, P, pb, b, n);

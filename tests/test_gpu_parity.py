@@ -179,6 +179,31 @@ def test_traversal_schedule_same_results(built, name, monkeypatch):
     p2.close_render()
 
 
+@pytest.mark.parametrize("name", ["teapot_cornell", "grid_small", "stress_layout", "mesh_light", "env_sphere", "cornell_c1"])
+def test_setup_prepass_same_results(built, name, monkeypatch):
+    """k_prepare (the object walk up to a ray's first mesh as a streaming pass, used for large runs on scenes with meshes)
+    forced on for a small image: primary hits against the oracle, and radiance bit-identical to the in-kernel set-up."""
+    s, orc, pt, w, h = built(name)
+    monkeypatch.setenv("MI355PT_PREP_MIN_PATHS", "0")
+    p2 = PathTracer(pt.dscene)
+    p2.Init(w, h)
+    node, mesh, face, t = p2.trace_primary()
+    onode, omesh, oface, ot, _ = orc.trace_primary(pt.params, 0, 0, w, h)
+    assert np.array_equal(node, onode) and np.array_equal(mesh, omesh) and np.array_equal(face, oface)
+    assert np.array_equal(t.view(np.uint32), ot.view(np.uint32))
+    rng = np.random.default_rng(5)
+    pixel = rng.integers(0, w * h, 4000).astype(np.uint32)
+    sample = rng.integers(0, 32, 4000).astype(np.uint32)
+    a, _ = pt.sample_radiance(pixel, sample)
+    b, _ = p2.sample_radiance(pixel, sample)
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    p2.step(2); p2.sync()
+    pt.Init(w, h); pt.step(2); pt.sync()
+    assert np.array_equal(p2.read_accum()[0].view(np.uint32), pt.read_accum()[0].view(np.uint32))
+    assert p2.stats()["closest_rays"] > 0
+    p2.close_render()
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", ["teapot_cornell", "textured_c2"])
 def test_stream_overlap_same_results(built, name, monkeypatch):
