@@ -104,11 +104,60 @@ __device__ __forceinline__ uint32_t xcd_block(uint32_t b, uint32_t nb) {
     return (b & 7u) * per + (b >> 3);
 }
 
+// One ray of k_prepare (below): the object walk up to the first mesh `wr` must traverse.
+__device__ __forceinline__ void prepare_ray(const DScene& S, const DPaths& P, uint32_t slot, Ray wr) {
+    if (S.num_recs > 0) wr = rec_ray(S, S.recs, 1u, 0u, wr);
+    float best_t = kBig; int best_inst = -1;
+    uint32_t rec = 0;
+    bool found = false;
+    F3 o = f3(0, 0, 0), d = f3(0, 0, 0), inv = f3(0, 0, 0); uint32_t root_ref = 0, root_cnt = 0;
+    while (rec < (uint32_t)S.num_recs) {
+        const float4* R = S.recs + (size_t)rec * kRecStride;
+        const float4 h0 = R[0], h1 = R[1];
+        const uint32_t kind = __float_as_uint(h0.x), clen = __float_as_uint(h0.y), nexti = __float_as_uint(h0.z), rflags = __float_as_uint(h0.w);
+        const uint32_t rii = __float_as_uint(h1.x);
+        const Ray lr = rec_ray(S, R, clen, rii, wr, 1u);
+        if (kind != MI355PT_OBJ_MODEL) {
+            float t; bool front; F3 Pp;
+            const bool hit = kind == MI355PT_OBJ_PLANE ? plane_hit(lr.p, lr.d, SIDE_BOTH, t, front, Pp) : sphere_hit(lr.p, lr.d, SIDE_BOTH, t, front, Pp);
+            if (hit && t < best_t) { best_t = t; best_inst = (int)rii; }
+            rec = nexti;
+            continue;
+        }
+        const F3 linv = f3(1.0f, 1.0f, 1.0f) / lr.d;
+        const float4 b0 = R[2], b1 = R[3], b2 = R[4], b3 = R[5], b4 = R[6];
+        const float model_box[6] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y}, mesh_box[6] = {b1.z, b1.w, b2.x, b2.y, b2.z, b2.w};
+        const float root_box[6] = {b3.x, b3.y, b3.z, b3.w, b4.x, b4.y};
+        float tn;
+        const bool in_model = slab_straight(model_box, lr.p, linv, tn);
+        bool in_mesh = in_model, in_root;
+        if (!(rflags & 2u)) in_mesh = slab_straight(mesh_box, lr.p, linv, tn);
+        in_root = in_mesh;
+        if (!(rflags & 4u)) in_root = slab_straight(root_box, lr.p, linv, tn);
+        if ((rflags & 1u) && !in_model) { rec = nexti; continue; }
+        const uint32_t rc = __float_as_uint(h1.w);
+        bool go = in_mesh;
+        if (go && rc == kInternal) go = in_root;
+        if (go && rc == 0u) go = false;
+        if (!go) { rec++; continue; }
+        found = true; o = lr.p; d = lr.d; inv = linv; root_ref = __float_as_uint(h1.z); root_cnt = rc;
+        break;
+    }
+    float4* A = P.prep + 4 * (size_t)slot;
+    if (found) {
+        A[0] = make_float4(o.x, o.y, o.z, best_t); A[1] = make_float4(d.x, d.y, d.z, __int_as_float(best_inst));
+        A[2] = make_float4(inv.x, inv.y, inv.z, __uint_as_float(rec)); A[3] = make_float4(__uint_as_float(root_ref), __uint_as_float(root_cnt), 0.0f, 0.0f);
+    } else {
+        store_hit(P, slot, best_t, best_inst, -1, 0u);
+        A[2] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(0xFFFFFFFFu));
+    }
+}
+
 // ---------------------------------------------------------------------- init
 __global__ void __launch_bounds__(kBlock) k_init(DPaths P, Params prm, uint32_t n, uint32_t pix_base, uint32_t npix_chunk,
                                                  const uint32_t* cnt, uint32_t sample_offset, uint32_t sample_stride,
                                                  const uint32_t* list_pix, const uint32_t* list_smp, const uint32_t* own,
-                                                 DCamera cam, uint32_t with_rays) {
+                                                 DCamera cam, uint32_t with_rays, DScene S) {
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         uint32_t pixel, sample;
         if (list_pix) { pixel = list_pix[i]; sample = list_smp[i]; }
@@ -124,6 +173,7 @@ __global__ void __launch_bounds__(kBlock) k_init(DPaths P, Params prm, uint32_t 
             Ray r; F3 rd, td;
             camera_rays(cam, prm.seed, pixel, sample, prm.width, true, r, rd, td);
             P.ray[2 * (size_t)i] = f4(r.p, 0.0f); P.ray[2 * (size_t)i + 1] = f4(r.d, 0.0f);
+            if (with_rays == 2u) prepare_ray(S, P, i, r);       // bounce 0's set-up pre-pass in the same pass (k_prepare)
         }
     }
 }
@@ -199,51 +249,7 @@ __global__ void __launch_bounds__(kBlock) k_prepare(DScene S, DPaths P, uint32_t
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const uint32_t slot = q ? q[i] : i;
         Ray wr; wr.p = xyz(P.ray[2 * (size_t)slot]); wr.d = xyz(P.ray[2 * (size_t)slot + 1]);
-        if (S.num_recs > 0) wr = rec_ray(S, S.recs, 1u, 0u, wr);
-        float best_t = kBig; int best_inst = -1;
-        uint32_t rec = 0;
-        bool found = false;
-        F3 o = f3(0, 0, 0), d = f3(0, 0, 0), inv = f3(0, 0, 0); uint32_t root_ref = 0, root_cnt = 0;
-        while (rec < (uint32_t)S.num_recs) {
-            const float4* R = S.recs + (size_t)rec * kRecStride;
-            const float4 h0 = R[0], h1 = R[1];
-            const uint32_t kind = __float_as_uint(h0.x), clen = __float_as_uint(h0.y), nexti = __float_as_uint(h0.z), rflags = __float_as_uint(h0.w);
-            const uint32_t rii = __float_as_uint(h1.x);
-            const Ray lr = rec_ray(S, R, clen, rii, wr, 1u);
-            if (kind != MI355PT_OBJ_MODEL) {
-                float t; bool front; F3 Pp;
-                const bool hit = kind == MI355PT_OBJ_PLANE ? plane_hit(lr.p, lr.d, SIDE_BOTH, t, front, Pp) : sphere_hit(lr.p, lr.d, SIDE_BOTH, t, front, Pp);
-                if (hit && t < best_t) { best_t = t; best_inst = (int)rii; }
-                rec = nexti;
-                continue;
-            }
-            const F3 linv = f3(1.0f, 1.0f, 1.0f) / lr.d;
-            const float4 b0 = R[2], b1 = R[3], b2 = R[4], b3 = R[5], b4 = R[6];
-            const float model_box[6] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y}, mesh_box[6] = {b1.z, b1.w, b2.x, b2.y, b2.z, b2.w};
-            const float root_box[6] = {b3.x, b3.y, b3.z, b3.w, b4.x, b4.y};
-            float tn;
-            const bool in_model = slab_straight(model_box, lr.p, linv, tn);
-            bool in_mesh = in_model, in_root;
-            if (!(rflags & 2u)) in_mesh = slab_straight(mesh_box, lr.p, linv, tn);
-            in_root = in_mesh;
-            if (!(rflags & 4u)) in_root = slab_straight(root_box, lr.p, linv, tn);
-            if ((rflags & 1u) && !in_model) { rec = nexti; continue; }
-            const uint32_t rc = __float_as_uint(h1.w);
-            bool go = in_mesh;
-            if (go && rc == kInternal) go = in_root;
-            if (go && rc == 0u) go = false;
-            if (!go) { rec++; continue; }
-            found = true; o = lr.p; d = lr.d; inv = linv; root_ref = __float_as_uint(h1.z); root_cnt = rc;
-            break;
-        }
-        float4* A = P.prep + 4 * (size_t)slot;
-        if (found) {
-            A[0] = make_float4(o.x, o.y, o.z, best_t); A[1] = make_float4(d.x, d.y, d.z, __int_as_float(best_inst));
-            A[2] = make_float4(inv.x, inv.y, inv.z, __uint_as_float(rec)); A[3] = make_float4(__uint_as_float(root_ref), __uint_as_float(root_cnt), 0.0f, 0.0f);
-        } else {
-            store_hit(P, slot, best_t, best_inst, -1, 0u);
-            A[2] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(0xFFFFFFFFu));
-        }
+        prepare_ray(S, P, slot, wr);
     }
 }
 
@@ -1556,7 +1562,11 @@ void drain_events(mi355pt_render* r) {
 }
 
 // The bounce loop for `n` initialised path slots.
-int run_paths(mi355pt_render* r, uint32_t n, uint32_t jitter = 1, uint32_t only_extend = 0) {
+bool use_prepass(const mi355pt_render* r, uint32_t n) {
+    return !r->count_work && r->prep_bounces > 0 && r->scene->num_tris > 0 && n >= r->prep_min_paths;
+}
+
+int run_paths(mi355pt_render* r, uint32_t n, uint32_t jitter = 1, uint32_t only_extend = 0, bool prep0_done = false) {
     DPaths& P = r->P; const mi355pt_render_params& p = r->prm;
     const DScene& S = r->scene->d;
     Params prm{p.seed, p.width, p.height, p.max_bounces, p.rr_start, r->stack_entries, r->node_lanes, r->owner_lanes, ++r->gen};
@@ -1570,8 +1580,8 @@ int run_paths(mi355pt_render* r, uint32_t n, uint32_t jitter = 1, uint32_t only_
         // The pre-pass pays where most rays go on to traverse a mesh and the launch is large (C4: -0.6 ms); it costs a launch
         // and 96 B per ray, which lost 4-13 % on the all-analytic C1 / C3 and on the 2 M-path C2.  Counting builds count
         // the walk's root-bound visits in the kernel.
-        pb.use_prep = (!r->count_work && b < r->prep_bounces && r->scene->num_tris > 0 && n >= r->prep_min_paths) ? 1u : 0u;
-        if (pb.use_prep) hipLaunchKernelGGL(k_prepare, dim3(g), dim3(kBlock), 0, r->stream, S, P, b, n);
+        pb.use_prep = (b < r->prep_bounces && use_prepass(r, n)) ? 1u : 0u;
+        if (pb.use_prep && !(b == 0 && prep0_done)) hipLaunchKernelGGL(k_prepare, dim3(g), dim3(kBlock), 0, r->stream, S, P, b, n);
         ev_begin(r, 0, r->stream);
         if (r->count_work) hipLaunchKernelGGL((k_trace<0, true>), dim3(ge), dim3(kExtBlock), r->extend_lds, r->stream, S, P, pb, b, n);
         else hipLaunchKernelGGL((k_trace<0, false>), dim3(ge), dim3(kExtBlock), r->extend_lds, r->stream, S, P, pb, b, n);
@@ -1648,9 +1658,9 @@ int mi355pt_render_step(mi355pt_render* r, uint32_t spp) {
             const uint32_t n = np * ns;
             ev_begin(r, 3, r->stream);
             hipLaunchKernelGGL(k_init, dim3(grid_for(r, n)), dim3(kBlock), 0, r->stream, r->P, kprm,
-                               n, (uint32_t)pix_base, np, r->cnt, p.sample_offset, p.sample_stride, (const uint32_t*)nullptr, (const uint32_t*)nullptr, (const uint32_t*)r->own, r->cam, 1u);
+                               n, (uint32_t)pix_base, np, r->cnt, p.sample_offset, p.sample_stride, (const uint32_t*)nullptr, (const uint32_t*)nullptr, (const uint32_t*)r->own, r->cam, use_prepass(r, n) ? 2u : 1u, r->scene->d);
             ev_end(r, r->stream);
-            if (int rc = run_paths(r, n, 2u)) return rc;
+            if (int rc = run_paths(r, n, 2u, 0u, use_prepass(r, n))) return rc;
             ev_begin(r, 3, r->stream);
             hipLaunchKernelGGL(k_resolve, dim3(grid_for(r, np)), dim3(kBlock), 0, r->stream, r->P, r->mean, r->cnt, r->rgb8, (uint32_t)pix_base, np, ns, (const uint32_t*)r->own);
             ev_end(r, r->stream);
@@ -1768,8 +1778,8 @@ int mi355pt_sample_radiance(mi355pt_render* r, const uint32_t* pixel, const uint
     const mi355pt_render_params& p = r->prm;
     const Params kprm{p.seed, p.width, p.height, p.max_bounces, p.rr_start, r->stack_entries, r->node_lanes, r->owner_lanes};
     hipLaunchKernelGGL(k_init, dim3(grid_for(r, count)), dim3(kBlock), 0, r->stream, r->P, kprm,
-                       count, 0u, 1u, (const uint32_t*)r->cnt, 0u, 1u, (const uint32_t*)dp, (const uint32_t*)ds, (const uint32_t*)nullptr, r->cam, 1u);
-    int rc = run_paths(r, count, 2u);
+                       count, 0u, 1u, (const uint32_t*)r->cnt, 0u, 1u, (const uint32_t*)dp, (const uint32_t*)ds, (const uint32_t*)nullptr, r->cam, use_prepass(r, count) ? 2u : 1u, r->scene->d);
+    int rc = run_paths(r, count, 2u, 0u, use_prepass(r, count));
     hipLaunchKernelGGL(k_gather, dim3(grid_for(r, count)), dim3(kBlock), 0, r->stream, r->P, count, dl, dm);
     hipError_t e = hipStreamSynchronize(r->stream);
     if (e == hipSuccess && linear_rgb) e = hipMemcpy(linear_rgb, dl, (size_t)count * 12, hipMemcpyDeviceToHost);
