@@ -211,6 +211,12 @@ typedef struct mi355pt_stats {
 typedef struct mi355pt_scene  mi355pt_scene;    /* opaque: flattened scene in HBM      */
 typedef struct mi355pt_render mi355pt_render;   /* opaque: accumulator + path queues   */
 
+/* Thread contract.  Every entry point that takes a renderer locks it for the duration of the call, so one thread may
+ * run render_step / render_sync in a loop while another polls read_rgb8 / read_accum / stats, the way the reference's
+ * GUI thread polls renderImage every 0.3 s beside the tracing thread (src/window.cpp:170-174, src/raytracer.cpp:449);
+ * a poll waits for the step in flight.  A scene may be shared by several renderers; mi355pt_scene_destroy on a scene
+ * that still has renderers defers the release to the last mi355pt_render_destroy.  mi355pt_last_error is per thread. */
+
 /* Library / device. */
 const char* mi355pt_version(void);
 const char* mi355pt_last_error(void);
@@ -284,6 +290,12 @@ int mi355pt_trace_rays(mi355pt_render* render, const float* origins, const float
                        int32_t* node, int32_t* mesh, int32_t* face, float* t);
 int mi355pt_sample_radiance(mi355pt_render* render, const uint32_t* pixel, const uint32_t* sample,
                             uint32_t count, float* linear_rgb, float* mapped_rgb);
+/*  - trace_visibility: LightVisTest (src/raytracer.cpp:132-152) toward light `light` (index into lights[]) for
+ *    `count` arbitrary world-space rays with their own t_max, through the production visibility kernels (the
+ *    light's own object both sides first, then every other object's front faces).  blocked[i] = 1 when the
+ *    reference's LightVisTest returns true (occluded, light missed, or light met from behind), else 0.    */
+int mi355pt_trace_visibility(mi355pt_render* render, const float* origins, const float* dirs, const float* tmax,
+                             int32_t light, uint32_t count, uint8_t* blocked);
 
 int mi355pt_render_stats(mi355pt_render* render, mi355pt_stats* stats);
 int mi355pt_render_reset_stats(mi355pt_render* render);

@@ -34,6 +34,7 @@ def lib():
         L.oracle_sample_radiance.argtypes = [vp, C.POINTER(capi.RenderParams), C.c_void_p, C.c_void_p, capi.u32, C.c_void_p, C.c_void_p]
         L.oracle_render.argtypes = [vp, C.POINTER(capi.RenderParams)] + [capi.u32] * 6 + [C.c_void_p] * 4
         L.oracle_trace_rays.argtypes = [vp, C.c_void_p, C.c_void_p, capi.u32] + [C.c_void_p] * 4
+        L.oracle_light_vis.argtypes = [vp, C.c_void_p, C.c_void_p, C.c_void_p, capi.i32, capi.u32, C.c_void_p]
         L.oracle_rng_u31.restype = capi.u32
         L.oracle_rng_u31.argtypes = [capi.u32] * 4
         L.oracle_halton.restype = C.c_float
@@ -85,6 +86,14 @@ class OracleScene:
         t = np.zeros(n, dtype=np.float32)
         lib().oracle_trace_rays(self.h, _p(origins), _p(dirs), n, _p(node), _p(mesh), _p(face), _p(t))
         return node, mesh, face, t
+
+    def light_vis(self, origins, dirs, tmax, light=0):
+        origins = np.ascontiguousarray(origins, dtype=np.float32)
+        dirs = np.ascontiguousarray(dirs, dtype=np.float32)
+        tmax = np.ascontiguousarray(tmax, dtype=np.float32)
+        blocked = np.zeros(origins.shape[0], dtype=np.uint8)
+        assert lib().oracle_light_vis(self.h, _p(origins), _p(dirs), _p(tmax), int(light), origins.shape[0], _p(blocked)) == 0
+        return blocked
 
     def count_ordered_primary(self, params, x0, y0, x1, y1):
         n = (x1 - x0) * (y1 - y0)

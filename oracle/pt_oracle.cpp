@@ -19,8 +19,8 @@
 // by the environment as a stand-in build ("Oracle pin status").  This
 // restatement therefore rests on a line-by-line reading of the reference sources (each
 // function cites the file:line it follows) and on known-answer / property checks in
-// tests/test_oracle_properties.py; nothing here has been compared with output of the
-// reference itself.
+// tests/test_oracle.py and tests/test_bvh_builder.py; nothing here has been compared with output
+// of the reference itself (second-hand pins: the survey's recorded probe values).
 //
 // The only deliberate departure from the reference: libc rand() is replaced by the
 // counter-based generator pt_rng (keyed seed/pixel/sample/draw#), as north_star asks
@@ -155,7 +155,7 @@ inline V3 g_mul(const GM3& M, V3 v) {
 // Stand-in for libc rand() (all call sites listed in SURVEY section 8a row R).
 // Counter-based: r = hash(seed, pixel, sample, draw#) >> 1, a 31-bit int like rand();
 // U() = (float)r / (float)RAND_MAX with RAND_MAX = 2^31-1 (so 1.0 is reachable).
-// The product implements the same specification independently (csrc/pt_rng.h).
+// The product implements the same specification independently (struct Rng, pathtracer_amd/csrc/pt_device.h).
 inline uint32_t fmix32(uint32_t h) {
     h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16; return h;
 }
@@ -1541,6 +1541,18 @@ int oracle_trace_rays(const oracle_scene* o, const float* origins, const float* 
     return 0;
 }
 
+// LightVisTest (src/raytracer.cpp:132-152) toward lights[light] for arbitrary world-space rays: blocked[i] = its return value.
+int oracle_light_vis(const oracle_scene* o, const float* origins, const float* dirs, const float* tmax, int32_t light, uint32_t count, uint8_t* blocked) {
+    const Scene& sc = o->sc;
+    if (light < 0 || (size_t)light >= sc.lights.size()) return -1;
+    for (uint32_t i = 0; i < count; i++) {
+        Ray r; r.p = rd3(origins + 3 * i); r.dir = rd3(dirs + 3 * i);
+        HitInfo h;
+        blocked[i] = LightVisTest(sc, r, h, tmax[i], sc.lights[light].node) ? 1 : 0;
+    }
+    return 0;
+}
+
 // Ordered-traversal counters for the same primary rays (single-model scenes; SURVEY 8d n_node/n_tri).
 int oracle_count_ordered_primary(const oracle_scene* o, const mi355pt_render_params* prm, uint32_t x0, uint32_t y0, uint32_t x1, uint32_t y1,
                                  uint64_t* counters, int32_t* face_out) {
@@ -1642,7 +1654,7 @@ int oracle_render(const oracle_scene* o, const mi355pt_render_params* prm, uint3
     return 0;
 }
 
-// ---- small pieces exposed for the oracle-vs-reference-pieces tests (tests/test_oracle_vs_ref_pieces.py)
+// ---- small pieces exposed for the oracle-vs-reference-pieces tests (tests/test_oracle.py)
 void oracle_aces(const float in[3], float out[3]) { V3 r = ACES(rd3(in)); out[0] = r.x; out[1] = r.y; out[2] = r.z; }
 float oracle_halton(int index, int base) { return Halton(index, base); }
 int oracle_box_intersect(const float box[6], const float p[3], const float d[3]) { Ray r; r.p = rd3(p); r.dir = rd3(d); return BoxIntersectRay(box, r) ? 1 : 0; }

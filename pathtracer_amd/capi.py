@@ -104,6 +104,7 @@ SYMBOLS = [
     "mi355pt_render_read_rgb8", "mi355pt_render_read_accum", "mi355pt_render_write_accum",
     "mi355pt_render_accum_device_ptrs", "mi355pt_trace_primary", "mi355pt_trace_rays", "mi355pt_sample_radiance",
     "mi355pt_render_stats", "mi355pt_render_reset_stats", "mi355pt_render_set_profiling", "mi355pt_render_set_overlap", "mi355pt_render_stream",
+    "mi355pt_trace_visibility",
 ]
 
 _lib = None
@@ -148,6 +149,7 @@ def load_library(path=None):
     lib.mi355pt_render_set_overlap.argtypes = [vp, C.c_uint32]
     lib.mi355pt_render_stream.argtypes = [vp]
     lib.mi355pt_render_stream.restype = vp
+    lib.mi355pt_trace_visibility.argtypes = [vp, C.c_void_p, C.c_void_p, C.c_void_p, i32, u32, C.c_void_p]
     if path is None:
         _lib = lib
     return lib

@@ -317,6 +317,12 @@ void flatten_tree(const MeshTree& t, FlatMesh& out) {
         out.node_words.resize(out.node_words.size() + 16 * links, 0.0f);
         for (size_t l = 0; l < links; l++) {
             const size_t w = 16 * (base + l);
+            // The node step evaluates both child slabs of every record it pops and culls a child whose slab is hit
+            // beyond the current best.  A chain record's children have no bound in the reference (they are pieces of
+            // ONE leaf, tested unconditionally): NaN bounds make every slab comparison false, i.e. "hit, entry
+            // distance NaN", and NaN > limit is false, so a piece is never culled (an all-zero box could be "hit"
+            // by a ray through the mesh-space origin and then culled by distance).
+            for (int k = 0; k < 12; k++) put_u(w + k, 0x7FC00000u);
             put_u(w + 12, first); put_u(w + 14, kMaxLeaf);
             first += kMaxLeaf; cnt -= kMaxLeaf;
             if (l + 1 < links) { put_u(w + 13, (uint32_t)(base + l + 1)); put_u(w + 15, kChain); }

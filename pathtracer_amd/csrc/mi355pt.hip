@@ -65,7 +65,7 @@ struct DPaths {
     uint32_t *spill_any;  // the same for k_trace<ANY>, which may run beside k_trace<closest> of the next bounce
     unsigned long long *stat;   // [0] closest rays [1] shadow rays [2] samples [3,4] extend node visits / tri tests [5,6] visibility ditto [7] guard
 };
-struct Params { uint32_t seed, width, height, max_bounces, rr_start, stack_entries, node_lanes, owner_lanes, gen, use_prep; };
+struct Params { uint32_t seed, width, height, max_bounces, rr_start, stack_entries, node_lanes, owner_lanes, gen, use_prep, no_cull; };
 
 __device__ __forceinline__ F3 xyz(float4 v) { return f3(v.x, v.y, v.z); }
 __device__ __forceinline__ float4 f4(F3 v, float w) { return make_float4(v.x, v.y, v.z, w); }
@@ -277,6 +277,11 @@ __global__ void __launch_bounds__(kExtBlock) k_trace(DScene S, DPaths P, Params 
     uint32_t* nwork = aux + kLdsWork;                            // [64] lanes still walking for this owner
     uint32_t* xfer = aux + kLdsXfer;                             // [128] steal hand-over
     uint8_t* tril = (uint8_t*)(aux + kLdsTri);                   // [256] expanded triangle list of one drain round
+    // [64] per owner: the largest rounding-error bound of any candidate accepted for its ray so far (float bits; see
+    // tri_closest_key).  A grazing hit's distance is noise of that size, and so is the distance the reference would
+    // compute for its coplanar neighbours in other subtrees: the distance cull must keep that far behind the best.
+    // It lives in the spare word of the owner's ray record (rayl[2 * owner + 1].w).
+#define PT_MARG(ow) (((uint32_t*)rayl)[8u * (ow) + 7u])
     // A lane's traversal stack is logical entries [sb, sp); the top `stack_entries` (a power of two) of them live in an
     // LDS ring, entries below `lo` in the wave's spill area in global memory.  Depth-first, near-child-first walks keep a
     // stack of about one entry per level with both children hit: the window is rarely left, and a 16-entry window instead
@@ -288,7 +293,7 @@ __global__ void __launch_bounds__(kExtBlock) k_trace(DScene S, DPaths P, Params 
     WorkCounters wc; wc.nodes = 0; wc.tris = 0;
     uint32_t state = LS_IDLE, slot = 0, rec = 0, sp = 0, sb = 0, lo = 0, owner = lane;
     F3 o = f3(0, 0, 0), inv = f3(0, 0, 0);
-    float bt = kBig, pabs = 0.0f;
+    float bt = kBig, pabs = 0.0f, bmarg = 0.0f;
     float best_t = kBig; int best_inst = -1, best_mesh = -1; uint32_t best_slot = 0;      // closest: best over the objects so far
     float bound = 0.0f; uint32_t linst = 0;                                                // any: distance bound, the light's object
     uint32_t rec_end = (uint32_t)S.num_recs;                                               // own: end of the light's records
@@ -363,10 +368,11 @@ __global__ void __launch_bounds__(kExtBlock) k_trace(DScene S, DPaths P, Params 
                                     p_o = f3(a0.x, a0.y, a0.z); p_d = f3(a1.x, a1.y, a1.z); p_inv = f3(a2.x, a2.y, a2.z);
                                     p_ref = __float_as_uint(a3.x); p_cnt = __float_as_uint(a3.y);
                                     best_t = a0.w; best_inst = __float_as_int(a1.w); best_mesh = -1; best_slot = 0;
+                                    PT_MARG(lane) = 0u;
                                 }
                             } else {
                             load_world(slot, wr);
-                            if (!ANY) { best_t = kBig; best_inst = -1; best_mesh = -1; best_slot = 0; }
+                            if (!ANY) { best_t = kBig; best_inst = -1; best_mesh = -1; best_slot = 0; PT_MARG(lane) = 0u; }
                             }
                             if (OWN) {
                                 const DLight& L = S.lights[__float_as_int(P.sh[(size_t)(slot >> 1) * kShVec + SHV_W1].w)];
@@ -416,11 +422,11 @@ __global__ void __launch_bounds__(kExtBlock) k_trace(DScene S, DPaths P, Params 
                     // the mesh starts from the best so far with slot key 0: an equal-t candidate of a later
                     // mesh / object loses (model.cpp:237), only a strictly closer one replaces it
                     rayl[2 * lane] = make_float4(lp.x, lp.y, lp.z, bound);
-                    rayl[2 * lane + 1] = make_float4(ld.x, ld.y, ld.z, 0.0f);
+                    rayl[2 * lane + 1] = make_float4(ld.x, ld.y, ld.z, ANY ? 0.0f : __uint_as_float(PT_MARG(lane)));
                     keyl[lane] = ANY ? 0ull : hit_key(best_t, 0u) & ~1ull;       // any: 1 = blocked
                     owner = lane; sb = 0; lo = 0;
                     if (root_cnt >= kChain) {
-                        o = lp; inv = linv; pabs = prune_abs(lp); bt = ANY ? bound : best_t;
+                        o = lp; inv = linv; pabs = prune_abs(lp); bt = ANY ? bound : best_t; bmarg = ANY ? 0.0f : __uint_as_float(PT_MARG(lane));
                         PT_STK(0) = root_ref; sp = 1; nwork[lane] = 1; state = LS_TRAV;
                     } else {
                         root_leaf = kLeafFlag | ((root_cnt - 1u) << 27) | root_ref;
@@ -540,7 +546,10 @@ __global__ void __launch_bounds__(kExtBlock) k_trace(DScene S, DPaths P, Params 
                         if (tzmin > tmin) tmin = tzmin;
                         hr = ok; tr = tmin;
                     }
-                    const float lim = bt * 1.0001f + pabs;              // beyond(): conservative distance cull, pt_device.h
+                    // conservative distance cull (pt_device.h, prune_abs); MI355PT_NO_CULL walks like the reference, with none
+                    // (no_cull == 2, MI355PT_CULL_PLAIN: round 1's cull without the candidates' error bound -- kept so that a test can
+                    // show the adversarial rays do break it)
+                    const float lim = prm.no_cull == 1u ? __uint_as_float(0x7F800000u) : (bt + (prm.no_cull == 2u ? 0.0f : bmarg)) * 1.0001f + pabs;
                     const bool farL = hl & (tl > lim), farR = hr & (tr > lim);
                     // internal children: entered iff their slab is hit (and not culled); chain records always
                     const bool pushL = (lcnt == kChain) | ((lcnt == kInternal) & hl & !farL);
@@ -609,8 +618,11 @@ __global__ void __launch_bounds__(kExtBlock) k_trace(DScene S, DPaths P, Params 
                     if (COUNT) wc.tris++;
                     if (ANY) { if (cur == 0ull && tri_any_front(T, f3(ro.x, ro.y, ro.z), f3(rd.x, rd.y, rd.z), ro.w)) keyl[own[u]] = 1ull; }
                     else {
-                        unsigned long long ck;
-                        if (tri_closest_key(T, f3(ro.x, ro.y, ro.z), f3(rd.x, rd.y, rd.z), tslot[u], cur, ck)) atomicMin(&keyl[own[u]], ck);
+                        unsigned long long ck; float cerr;
+                        if (tri_closest_key(T, f3(ro.x, ro.y, ro.z), f3(rd.x, rd.y, rd.z), tslot[u], cur, ck, cerr)) {
+                            atomicMin(&keyl[own[u]], ck);
+                            atomicMax(&PT_MARG(own[u]), __float_as_uint(cerr));      // >= 0 or NaN: ordered as unsigned, NaN on top (= never cull)
+                        }
                     }
                 }
             }
@@ -621,7 +633,7 @@ __global__ void __launch_bounds__(kExtBlock) k_trace(DScene S, DPaths P, Params 
         // ================= after the drain: refresh pruning distances, finish meshes, steal
         if (state == LS_TRAV || state == LS_THIEF) {
             const unsigned long long k = keyl[owner];
-            if (!ANY) bt = __uint_as_float((uint32_t)(k >> 32));
+            if (!ANY) { bt = __uint_as_float((uint32_t)(k >> 32)); bmarg = __uint_as_float(PT_MARG(owner)); }
             else if (k) { sp = sb; lo = sb; atomicSub(&nwork[owner], 1u); state = state == LS_TRAV ? LS_WAIT : (exhausted ? LS_DONE : LS_IDLE); }   // blocked: abandon the walk
         }
         __syncthreads();
@@ -664,7 +676,7 @@ __global__ void __launch_bounds__(kExtBlock) k_trace(DScene S, DPaths P, Params 
                         owner = xfer[64 + r];
                         const float4 ro = rayl[2 * owner], rd = rayl[2 * owner + 1];
                         o = f3(ro.x, ro.y, ro.z); inv = f3(1.0f, 1.0f, 1.0f) / f3(rd.x, rd.y, rd.z); pabs = prune_abs(o);
-                        bt = ANY ? ro.w : __uint_as_float((uint32_t)(keyl[owner] >> 32));
+                        bt = ANY ? ro.w : __uint_as_float((uint32_t)(keyl[owner] >> 32)); bmarg = ANY ? 0.0f : __uint_as_float(PT_MARG(owner));
                         PT_STK(0) = xfer[r]; sp = 1; sb = 0; lo = 0; state = LS_THIEF;
                     }
                 }
@@ -674,6 +686,7 @@ __global__ void __launch_bounds__(kExtBlock) k_trace(DScene S, DPaths P, Params 
         PT_PHASE(ck_rest);
     }
 #undef PT_STK
+#undef PT_MARG
 #undef PT_SPILL
 #undef PT_PHASE
     if (COUNT) { wave_add64(wc.nodes, &P.stat[MODE ? 5 : 3]); wave_add64(wc.tris, &P.stat[MODE ? 6 : 4]);
@@ -1036,6 +1049,9 @@ struct mi355pt_scene {
     DevBuf<float4> bvh_nodes, tris, attrs, recs; DevBuf<uint32_t> faces; DevBuf<float> normals, uvw, tangents, bitangents;
     DevBuf<mi355pt_material> materials; DevBuf<mi355pt_texmap> texmaps; DevBuf<DTexture> textures; DevBuf<DLight> lights; DevBuf<float> light_data;
     bool model_lights = false;        // some light sits on a Model: its own-object test is a BVH traversal (k_trace<2>)
+    // Renderers keep a pointer to their scene: scene_destroy while some are alive only marks the scene, and the last
+    // render_destroy frees it (a reference maintainer's Restart() tears things down in whatever order it likes).
+    std::mutex life; int renderers = 0; bool doomed = false;
     std::vector<void*> tex_data;
     uint64_t num_tris = 0, num_bvh_nodes = 0; int max_depth = 0;
     ~mi355pt_scene() {
@@ -1048,6 +1064,11 @@ struct mi355pt_scene {
 
 struct mi355pt_render {
     mi355pt_scene* scene = nullptr;
+    int device = 0;
+    // Thread contract (include/mi355pt.h): every entry point that takes a renderer locks it, so a GUI thread may poll
+    // read_rgb8 / stats while another thread runs step / sync, as the reference's window does (window.cpp:170-174).
+    std::recursive_mutex mu;
+    void* hook = nullptr; size_t hook_bytes = 0;    // device staging of the parity hooks' outputs, grown on demand and kept
     mi355pt_render_params prm{};
     DCamera cam{};
     DPaths P{};
@@ -1066,6 +1087,7 @@ struct mi355pt_render {
     float* mean = nullptr; uint32_t* cnt = nullptr; uint8_t* rgb8 = nullptr;
     uint32_t* own = nullptr; size_t n_own = 0;       // tile split: the pixels this renderer renders (nullptr = all)
     int profiling = 0;                              // 0 none, 1 = events around k_trace<closest> only, 2 = around every stage
+    uint32_t no_cull = 0;                           // MI355PT_NO_CULL: walk every box the ray's line meets, like the reference (verification)
     bool count_work = false;
     struct Ev { hipEvent_t a, b; int kind; };
     std::vector<Ev> events; bool ev_open = false;
@@ -1076,6 +1098,7 @@ struct mi355pt_render {
         for (hipEvent_t e : fork) (void)hipEventDestroy(e);
         for (hipEvent_t e : join) (void)hipEventDestroy(e);
         for (void* p : allocs) (void)hipFree(p);
+        if (hook) (void)hipFree(hook);
         if (side) (void)hipStreamDestroy(side);
         if (progress) (void)hipHostFree(progress);
         if (stream) (void)hipStreamDestroy(stream);
@@ -1148,6 +1171,9 @@ int mi355pt_scene_create(const mi355pt_scene_desc* desc, int32_t device, mi355pt
         memcpy(d.tm, s.tm, sizeof(d.tm)); memcpy(d.itm, s.itm, sizeof(d.itm)); memcpy(d.pos, s.pos, sizeof(d.pos));
         memcpy(d.l2w, s.local_to_world, sizeof(d.l2w));
         d.material = s.material; d.light = s.light; d.pad0 = d.pad1 = 0;
+        // Node::GetLight() <-> LightComponent::parent must point at each other: the kernels index lights[] with node.light
+        if (s.light < -1 || s.light >= (int32_t)desc->num_lights) return fail(MI355PT_ERR_INVALID, "node.light out of range");
+        if (s.light >= 0 && (!desc->lights || desc->lights[s.light].node != (int32_t)i)) return fail(MI355PT_ERR_INVALID, "lights[node.light].node must be that node");
         if (s.object_kind == MI355PT_OBJ_NONE) continue;
         if (s.object_kind != MI355PT_OBJ_PLANE && s.object_kind != MI355PT_OBJ_SPHERE && s.object_kind != MI355PT_OBJ_MODEL) return fail(MI355PT_ERR_UNSUPPORTED, "unknown object kind");
         if (s.material < 0 || (uint32_t)s.material >= desc->num_materials) return fail(MI355PT_ERR_INVALID, "object node without material");
@@ -1174,6 +1200,7 @@ int mi355pt_scene_create(const mi355pt_scene_desc* desc, int32_t device, mi355pt
         const mi355pt_light& s = desc->lights[i];
         if (s.node < 0 || (uint32_t)s.node >= desc->num_nodes || desc->nodes[s.node].object_kind == MI355PT_OBJ_NONE)
             return fail(MI355PT_ERR_INVALID, "a light's node must carry an object (LightComponent::parent->GetNodeObj())");
+        if (desc->nodes[s.node].light != (int32_t)i) return fail(MI355PT_ERR_INVALID, "nodes[light.node].light must be that light");
         const mi355pt_node& ln = desc->nodes[s.node];
         DLight& d = lights[i];
         memset(&d, 0, sizeof(d));
@@ -1379,7 +1406,15 @@ int mi355pt_scene_create(const mi355pt_scene_desc* desc, int32_t device, mi355pt
     return MI355PT_OK;
 }
 
-void mi355pt_scene_destroy(mi355pt_scene* scene) { if (scene) { (void)hipSetDevice(scene->device); delete scene; } }
+void mi355pt_scene_destroy(mi355pt_scene* scene) {
+    if (!scene) return;
+    {   // renderers still hold this scene: the last one to go frees it
+        std::lock_guard<std::mutex> g(scene->life);
+        if (scene->renderers > 0) { scene->doomed = true; return; }
+    }
+    (void)hipSetDevice(scene->device);
+    delete scene;
+}
 
 int mi355pt_scene_get_bvh(const mi355pt_scene* scene, uint32_t mesh, mi355pt_bvh_node* nodes, uint32_t* num_nodes, uint32_t* faces, uint32_t* num_faces) {
     if (!scene || mesh >= scene->trees.size() || !num_nodes || !num_faces) return fail(MI355PT_ERR_INVALID, "bad argument");
@@ -1415,9 +1450,10 @@ int mi355pt_render_create(mi355pt_scene* scene, const mi355pt_render_params* par
     if (params->width == 0 || params->height == 0 || params->max_bounces == 0 || params->sample_stride == 0) return fail(MI355PT_ERR_INVALID, "bad render parameters");
     if ((uint64_t)params->width * params->height > 0x7FFFFFFFull) return fail(MI355PT_ERR_TOO_LARGE, "image too large");
     if (params->device != scene->device) return fail(MI355PT_ERR_INVALID, "renderer and scene must be on the same device");
+    { std::lock_guard<std::mutex> g(scene->life); if (scene->doomed) return fail(MI355PT_ERR_INVALID, "the scene has been destroyed"); }
     HIP_TRY(hipSetDevice(scene->device));
     std::unique_ptr<mi355pt_render> r(new mi355pt_render());
-    r->scene = scene; r->prm = *params;
+    r->scene = scene; r->device = scene->device; r->prm = *params;
     r->cam = init_camera(scene->camera, params->width, params->height);
     {   // the main stream carries the critical path (closest-hit trace -> shade): it gets the higher priority, the side
         // stream's visibility traces take what is left
@@ -1514,26 +1550,46 @@ int mi355pt_render_create(mi355pt_scene* scene, const mi355pt_render_params* par
     if (const char* e = getenv("MI355PT_NODE_LANES")) r->node_lanes = (uint32_t)std::min(64, std::max(1, atoi(e)));
     if (const char* e = getenv("MI355PT_OWNER_LANES")) r->owner_lanes = (uint32_t)std::min(64, std::max(1, atoi(e)));
     r->count_work = getenv("MI355PT_COUNT_WORK") != nullptr;
+    r->no_cull = getenv("MI355PT_NO_CULL") ? 1u : (getenv("MI355PT_CULL_PLAIN") ? 2u : 0u);
     if (!getenv("MI355PT_NO_EARLY_STOP")) {
         HIP_TRY(hipHostMalloc((void**)&r->progress, nb * sizeof(unsigned long long), hipHostMallocMapped | hipHostMallocCoherent));
         memset(r->progress, 0, nb * sizeof(unsigned long long));
         HIP_TRY(hipHostGetDevicePointer((void**)&P.progress, r->progress, 0));
     }
     if (getenv("MI355PT_VERBOSE")) fprintf(stderr, "mi355pt: tree depth %d, extend grid %d waves, LDS %zu B/wave\n", scene->max_depth, r->extend_grid, r->extend_lds);
+    { std::lock_guard<std::mutex> g(scene->life); scene->renderers++; }
     *out = r.release();
     return MI355PT_OK;
 }
 
 void mi355pt_render_destroy(mi355pt_render* render) {
     if (!render) return;
-    (void)hipSetDevice(render->scene->device);
-    (void)hipStreamSynchronize(render->stream);
+    mi355pt_scene* sc = render->scene;
+    {
+        std::lock_guard<std::recursive_mutex> lk(render->mu);
+        (void)hipSetDevice(render->device);
+        (void)hipStreamSynchronize(render->stream);
+        if (render->side) (void)hipStreamSynchronize(render->side);
+    }
     delete render;
+    bool last = false;
+    { std::lock_guard<std::mutex> g(sc->life); sc->renderers--; last = sc->doomed && sc->renderers == 0; }
+    if (last) delete sc;
 }
 
 }  // extern "C"
 
 namespace {
+
+// device staging for the parity hooks' outputs: one allocation per renderer, grown on demand, freed with the renderer
+int ensure_hook(mi355pt_render* r, size_t bytes) {
+    if (bytes <= r->hook_bytes) return MI355PT_OK;
+    if (r->hook) { (void)hipFree(r->hook); r->hook = nullptr; r->hook_bytes = 0; }
+    HIP_TRY(hipMalloc(&r->hook, bytes));
+    r->hook_bytes = bytes;
+    return MI355PT_OK;
+}
+#define PT_LOCK(r) std::lock_guard<std::recursive_mutex> lk_((r)->mu)
 
 int grid_for(const mi355pt_render* r, size_t n) {
     size_t b = (n + kBlock - 1) / kBlock;
@@ -1569,7 +1625,7 @@ bool use_prepass(const mi355pt_render* r, uint32_t n) {
 int run_paths(mi355pt_render* r, uint32_t n, uint32_t jitter = 1, uint32_t only_extend = 0, bool prep0_done = false) {
     DPaths& P = r->P; const mi355pt_render_params& p = r->prm;
     const DScene& S = r->scene->d;
-    Params prm{p.seed, p.width, p.height, p.max_bounces, p.rr_start, r->stack_entries, r->node_lanes, r->owner_lanes, ++r->gen};
+    Params prm{p.seed, p.width, p.height, p.max_bounces, p.rr_start, r->stack_entries, r->node_lanes, r->owner_lanes, ++r->gen, 0u, r->no_cull};
     HIP_TRY(hipMemsetAsync(r->ctr, 0, r->ctr_bytes, r->stream));     // counts, svcounts, work, vwork, lwork
     const int g = grid_for(r, n);
     const int ge = (int)std::max<size_t>(1, std::min<size_t>(((size_t)n + 63) / 64, (size_t)r->extend_grid));     // persistent: resident waves only
@@ -1644,7 +1700,8 @@ extern "C" {
 
 int mi355pt_render_step(mi355pt_render* r, uint32_t spp) {
     if (!r) return fail(MI355PT_ERR_INVALID, "null renderer");
-    HIP_TRY(hipSetDevice(r->scene->device));
+    PT_LOCK(r);
+    HIP_TRY(hipSetDevice(r->device));
     const mi355pt_render_params& p = r->prm;
     const size_t npix = r->own ? r->n_own : (size_t)p.width * p.height, cap = r->P.cap;
     if (npix == 0) return MI355PT_OK;
@@ -1672,7 +1729,8 @@ int mi355pt_render_step(mi355pt_render* r, uint32_t spp) {
 
 int mi355pt_render_sync(mi355pt_render* r) {
     if (!r) return fail(MI355PT_ERR_INVALID, "null renderer");
-    HIP_TRY(hipSetDevice(r->scene->device));
+    PT_LOCK(r);
+    HIP_TRY(hipSetDevice(r->device));
     HIP_TRY(hipStreamSynchronize(r->stream));
     drain_events(r);
     unsigned long long guard = 0;
@@ -1683,12 +1741,14 @@ int mi355pt_render_sync(mi355pt_render* r) {
 
 int mi355pt_render_read_rgb8(mi355pt_render* r, uint8_t* rgb) {
     if (!r || !rgb) return fail(MI355PT_ERR_INVALID, "null argument");
+    PT_LOCK(r);
     if (int rc = mi355pt_render_sync(r)) return rc;
     HIP_TRY(hipMemcpy(rgb, r->rgb8, (size_t)r->prm.width * r->prm.height * 3, hipMemcpyDeviceToHost));
     return MI355PT_OK;
 }
 int mi355pt_render_read_accum(mi355pt_render* r, float* mean_rgb, uint32_t* count) {
     if (!r) return fail(MI355PT_ERR_INVALID, "null argument");
+    PT_LOCK(r);
     if (int rc = mi355pt_render_sync(r)) return rc;
     const size_t npix = (size_t)r->prm.width * r->prm.height;
     if (mean_rgb) HIP_TRY(hipMemcpy(mean_rgb, r->mean, npix * 12, hipMemcpyDeviceToHost));
@@ -1697,6 +1757,7 @@ int mi355pt_render_read_accum(mi355pt_render* r, float* mean_rgb, uint32_t* coun
 }
 int mi355pt_render_write_accum(mi355pt_render* r, const float* mean_rgb, const uint32_t* count) {
     if (!r) return fail(MI355PT_ERR_INVALID, "null argument");
+    PT_LOCK(r);
     if (int rc = mi355pt_render_sync(r)) return rc;
     const size_t npix = (size_t)r->prm.width * r->prm.height;
     if (mean_rgb) HIP_TRY(hipMemcpy(r->mean, mean_rgb, npix * 12, hipMemcpyHostToDevice));
@@ -1713,23 +1774,24 @@ int mi355pt_render_accum_device_ptrs(mi355pt_render* r, void** mean_rgb, void** 
 int mi355pt_trace_primary(mi355pt_render* r, uint32_t x0, uint32_t y0, uint32_t x1, uint32_t y1, int32_t* node, int32_t* mesh, int32_t* face, float* t) {
     if (!r || !node || !mesh || !face || !t) return fail(MI355PT_ERR_INVALID, "null argument");
     if (x1 <= x0 || y1 <= y0 || x1 > r->prm.width || y1 > r->prm.height) return fail(MI355PT_ERR_INVALID, "bad rectangle");
-    HIP_TRY(hipSetDevice(r->scene->device));
+    PT_LOCK(r);
+    HIP_TRY(hipSetDevice(r->device));
     const uint32_t rw = x1 - x0, rh = y1 - y0; const size_t n = (size_t)rw * rh;
-    int32_t *dn, *dm, *df; float* dt;
-    HIP_TRY(hipMalloc((void**)&dn, n * 4)); HIP_TRY(hipMalloc((void**)&dm, n * 4)); HIP_TRY(hipMalloc((void**)&df, n * 4)); HIP_TRY(hipMalloc((void**)&dt, n * 4));
+    if (n > r->P.cap) return fail(MI355PT_ERR_TOO_LARGE, "rectangle larger than the path pool");
+    if (int rc = ensure_hook(r, n * 16)) return rc;
+    int32_t *dn = (int32_t*)r->hook, *dm = dn + n, *df = dm + n; float* dt = (float*)(df + n);
     const mi355pt_render_params& p = r->prm;
     Params prm{p.seed, p.width, p.height, p.max_bounces, p.rr_start, r->stack_entries, r->node_lanes, r->owner_lanes};
-    if (n > r->P.cap) { (void)hipFree(dn); (void)hipFree(dm); (void)hipFree(df); (void)hipFree(dt); return fail(MI355PT_ERR_TOO_LARGE, "rectangle larger than the path pool"); }
     hipLaunchKernelGGL(k_primary_init, dim3(grid_for(r, n)), dim3(kBlock), 0, r->stream, r->P, prm, x0, y0, rw, rh);
     const int rc = run_paths(r, (uint32_t)n, 0, 1);
-    hipLaunchKernelGGL(k_primary_out, dim3(grid_for(r, n)), dim3(kBlock), 0, r->stream, r->scene->d, r->P, (uint32_t)n, dn, dm, df, dt);
-    (void)rc;
+    if (rc == MI355PT_OK) hipLaunchKernelGGL(k_primary_out, dim3(grid_for(r, n)), dim3(kBlock), 0, r->stream, r->scene->d, r->P, (uint32_t)n, dn, dm, df, dt);
     hipError_t e = hipStreamSynchronize(r->stream);
+    drain_events(r);
+    if (rc) return rc;
     if (e == hipSuccess) e = hipMemcpy(node, dn, n * 4, hipMemcpyDeviceToHost);
     if (e == hipSuccess) e = hipMemcpy(mesh, dm, n * 4, hipMemcpyDeviceToHost);
     if (e == hipSuccess) e = hipMemcpy(face, df, n * 4, hipMemcpyDeviceToHost);
     if (e == hipSuccess) e = hipMemcpy(t, dt, n * 4, hipMemcpyDeviceToHost);
-    (void)hipFree(dn); (void)hipFree(dm); (void)hipFree(df); (void)hipFree(dt);
     HIP_TRY(e);
     return MI355PT_OK;
 }
@@ -1738,29 +1800,65 @@ int mi355pt_trace_rays(mi355pt_render* r, const float* origins, const float* dir
     if (!r || !origins || !dirs || !node || !mesh || !face || !t) return fail(MI355PT_ERR_INVALID, "null argument");
     if (count == 0) return MI355PT_OK;
     if (count > r->P.cap) return fail(MI355PT_ERR_TOO_LARGE, "more rays than path slots");
-    HIP_TRY(hipSetDevice(r->scene->device));
+    PT_LOCK(r);
+    HIP_TRY(hipSetDevice(r->device));
     const size_t n = count;
-    int32_t *dn, *dm, *df; float* dt;
-    HIP_TRY(hipMalloc((void**)&dn, n * 4)); HIP_TRY(hipMalloc((void**)&dm, n * 4)); HIP_TRY(hipMalloc((void**)&df, n * 4)); HIP_TRY(hipMalloc((void**)&dt, n * 4));
+    if (int rc = ensure_hook(r, n * 16)) return rc;
+    int32_t *dn = (int32_t*)r->hook, *dm = dn + n, *df = dm + n; float* dt = (float*)(df + n);
     std::vector<float4> rays(2 * n);
     for (size_t i = 0; i < n; i++) {
         rays[2 * i] = make_float4(origins[3 * i], origins[3 * i + 1], origins[3 * i + 2], 0.0f);
         rays[2 * i + 1] = make_float4(dirs[3 * i], dirs[3 * i + 1], dirs[3 * i + 2], 0.0f);
     }
-    hipError_t e = hipMemcpy(r->P.ray, rays.data(), rays.size() * sizeof(float4), hipMemcpyHostToDevice);
-    if (e == hipSuccess) {
-        const int rc = run_paths(r, (uint32_t)n, 2, 1);
-        (void)rc;
-        hipLaunchKernelGGL(k_primary_out, dim3(grid_for(r, n)), dim3(kBlock), 0, r->stream, r->scene->d, r->P, (uint32_t)n, dn, dm, df, dt);
-        e = hipStreamSynchronize(r->stream);
-    }
+    HIP_TRY(hipStreamSynchronize(r->stream));           // the path pool may still be in use by an earlier step
+    HIP_TRY(hipMemcpy(r->P.ray, rays.data(), rays.size() * sizeof(float4), hipMemcpyHostToDevice));
+    const int rc = run_paths(r, (uint32_t)n, 2, 1);
+    if (rc == MI355PT_OK) hipLaunchKernelGGL(k_primary_out, dim3(grid_for(r, n)), dim3(kBlock), 0, r->stream, r->scene->d, r->P, (uint32_t)n, dn, dm, df, dt);
+    hipError_t e = hipStreamSynchronize(r->stream);
+    drain_events(r);
+    if (rc) return rc;
     if (e == hipSuccess) e = hipMemcpy(node, dn, n * 4, hipMemcpyDeviceToHost);
     if (e == hipSuccess) e = hipMemcpy(mesh, dm, n * 4, hipMemcpyDeviceToHost);
     if (e == hipSuccess) e = hipMemcpy(face, df, n * 4, hipMemcpyDeviceToHost);
     if (e == hipSuccess) e = hipMemcpy(t, dt, n * 4, hipMemcpyDeviceToHost);
-    (void)hipFree(dn); (void)hipFree(dm); (void)hipFree(df); (void)hipFree(dt);
-    drain_events(r);
     HIP_TRY(e);
+    return MI355PT_OK;
+}
+
+int mi355pt_trace_visibility(mi355pt_render* r, const float* origins, const float* dirs, const float* tmax, int32_t light, uint32_t count, uint8_t* blocked) {
+    if (!r || !origins || !dirs || !tmax || !blocked) return fail(MI355PT_ERR_INVALID, "null argument");
+    if (count == 0) return MI355PT_OK;
+    if (count > r->P.cap) return fail(MI355PT_ERR_TOO_LARGE, "more rays than path slots");
+    if (light < 0 || light >= r->scene->d.num_lights) return fail(MI355PT_ERR_INVALID, "light index out of range");
+    PT_LOCK(r);
+    HIP_TRY(hipSetDevice(r->device));
+    const size_t n = count;
+    // one visibility item per ray, shaped like the ones k_shade queues for a light sample (item = slot * 2 + 0)
+    std::vector<float4> sh(kShVec * n, make_float4(0.0f, 0.0f, 0.0f, 0.0f));
+    std::vector<uint32_t> vq(n);
+    float lf; memcpy(&lf, &light, 4);
+    for (size_t i = 0; i < n; i++) {
+        sh[kShVec * i + SHV_O] = make_float4(origins[3 * i], origins[3 * i + 1], origins[3 * i + 2], tmax[i]);
+        sh[kShVec * i + SHV_W1] = make_float4(dirs[3 * i], dirs[3 * i + 1], dirs[3 * i + 2], lf);
+        vq[i] = (uint32_t)(2 * i);
+    }
+    HIP_TRY(hipStreamSynchronize(r->stream));
+    HIP_TRY(hipMemcpy(r->P.sh, sh.data(), sh.size() * sizeof(float4), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(r->P.vqueue, vq.data(), n * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemset(r->ctr, 0, r->ctr_bytes));
+    const unsigned long long sv = ((unsigned long long)count << 32) | (unsigned long long)count;
+    HIP_TRY(hipMemcpy(r->P.svcounts, &sv, sizeof(sv), hipMemcpyHostToDevice));
+    const mi355pt_render_params& p = r->prm;
+    Params prm{p.seed, p.width, p.height, p.max_bounces, p.rr_start, r->stack_entries, r->node_lanes, r->owner_lanes, ++r->gen, 0u, r->no_cull};
+    const int ge = (int)std::max<size_t>(1, std::min<size_t>((n + 63) / 64, (size_t)r->extend_grid));
+    const DScene& S = r->scene->d;
+    if (r->scene->model_lights) hipLaunchKernelGGL((k_trace<2, false>), dim3(ge), dim3(kExtBlock), r->extend_lds, r->stream, S, r->P, prm, 0u, count);
+    hipLaunchKernelGGL((k_trace<1, false>), dim3(ge), dim3(kExtBlock), r->extend_lds, r->stream, S, r->P, prm, 0u, count);
+    HIP_TRY(hipGetLastError());
+    if (int rc = mi355pt_render_sync(r)) return rc;
+    std::vector<uint8_t> vis(2 * n);
+    HIP_TRY(hipMemcpy(vis.data(), r->P.vis, 2 * n, hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < n; i++) blocked[i] = vis[2 * i];
     return MI355PT_OK;
 }
 
@@ -1770,29 +1868,30 @@ int mi355pt_sample_radiance(mi355pt_render* r, const uint32_t* pixel, const uint
     if (count > r->P.cap) return fail(MI355PT_ERR_TOO_LARGE, "more samples than path slots");
     const size_t npix = (size_t)r->prm.width * r->prm.height;
     for (uint32_t i = 0; i < count; i++) if (pixel[i] >= npix) return fail(MI355PT_ERR_INVALID, "pixel index out of range");
-    HIP_TRY(hipSetDevice(r->scene->device));
-    uint32_t *dp, *ds; float *dl, *dm;
-    HIP_TRY(hipMalloc((void**)&dp, (size_t)count * 4)); HIP_TRY(hipMalloc((void**)&ds, (size_t)count * 4));
-    HIP_TRY(hipMalloc((void**)&dl, (size_t)count * 12)); HIP_TRY(hipMalloc((void**)&dm, (size_t)count * 12));
+    PT_LOCK(r);
+    HIP_TRY(hipSetDevice(r->device));
+    if (int rc = ensure_hook(r, (size_t)count * 32)) return rc;
+    uint32_t *dp = (uint32_t*)r->hook, *ds = dp + count; float *dl = (float*)(ds + count), *dm = dl + 3 * (size_t)count;
+    HIP_TRY(hipStreamSynchronize(r->stream));
     HIP_TRY(hipMemcpy(dp, pixel, (size_t)count * 4, hipMemcpyHostToDevice)); HIP_TRY(hipMemcpy(ds, sample, (size_t)count * 4, hipMemcpyHostToDevice));
     const mi355pt_render_params& p = r->prm;
     const Params kprm{p.seed, p.width, p.height, p.max_bounces, p.rr_start, r->stack_entries, r->node_lanes, r->owner_lanes};
     hipLaunchKernelGGL(k_init, dim3(grid_for(r, count)), dim3(kBlock), 0, r->stream, r->P, kprm,
                        count, 0u, 1u, (const uint32_t*)r->cnt, 0u, 1u, (const uint32_t*)dp, (const uint32_t*)ds, (const uint32_t*)nullptr, r->cam, use_prepass(r, count) ? 2u : 1u, r->scene->d);
-    int rc = run_paths(r, count, 2u, 0u, use_prepass(r, count));
-    hipLaunchKernelGGL(k_gather, dim3(grid_for(r, count)), dim3(kBlock), 0, r->stream, r->P, count, dl, dm);
+    const int rc = run_paths(r, count, 2u, 0u, use_prepass(r, count));
+    if (rc == MI355PT_OK) hipLaunchKernelGGL(k_gather, dim3(grid_for(r, count)), dim3(kBlock), 0, r->stream, r->P, count, dl, dm);
     hipError_t e = hipStreamSynchronize(r->stream);
-    if (e == hipSuccess && linear_rgb) e = hipMemcpy(linear_rgb, dl, (size_t)count * 12, hipMemcpyDeviceToHost);
-    if (e == hipSuccess && mapped_rgb) e = hipMemcpy(mapped_rgb, dm, (size_t)count * 12, hipMemcpyDeviceToHost);
-    (void)hipFree(dp); (void)hipFree(ds); (void)hipFree(dl); (void)hipFree(dm);
     drain_events(r);
     if (rc) return rc;
+    if (e == hipSuccess && linear_rgb) e = hipMemcpy(linear_rgb, dl, (size_t)count * 12, hipMemcpyDeviceToHost);
+    if (e == hipSuccess && mapped_rgb) e = hipMemcpy(mapped_rgb, dm, (size_t)count * 12, hipMemcpyDeviceToHost);
     HIP_TRY(e);
     return MI355PT_OK;
 }
 
 int mi355pt_render_stats(mi355pt_render* r, mi355pt_stats* st) {
     if (!r || !st) return fail(MI355PT_ERR_INVALID, "null argument");
+    PT_LOCK(r);
     if (int rc = mi355pt_render_sync(r)) return rc;
     unsigned long long h[16];
     HIP_TRY(hipMemcpy(h, r->P.stat, sizeof(h), hipMemcpyDeviceToHost));
@@ -1805,6 +1904,7 @@ int mi355pt_render_stats(mi355pt_render* r, mi355pt_stats* st) {
 }
 int mi355pt_render_reset_stats(mi355pt_render* r) {
     if (!r) return fail(MI355PT_ERR_INVALID, "null argument");
+    PT_LOCK(r);
     if (int rc = mi355pt_render_sync(r)) return rc;
     HIP_TRY(hipMemsetAsync(r->P.stat, 0, 16 * sizeof(unsigned long long), r->stream));
     HIP_TRY(hipStreamSynchronize(r->stream));
@@ -1814,12 +1914,14 @@ int mi355pt_render_reset_stats(mi355pt_render* r) {
 }
 int mi355pt_render_set_overlap(mi355pt_render* r, uint32_t from_bounce) {
     if (!r) return fail(MI355PT_ERR_INVALID, "null renderer");
+    PT_LOCK(r);
     r->overlap_from = from_bounce;
     return MI355PT_OK;
 }
 
 int mi355pt_render_set_profiling(mi355pt_render* r, int enable_events, int count_work) {
     if (!r) return fail(MI355PT_ERR_INVALID, "null argument");
+    PT_LOCK(r);
     if (int rc = mi355pt_render_sync(r)) return rc;
     r->profiling = enable_events < 0 ? 0 : (enable_events > 2 ? 2 : enable_events); r->count_work = count_work != 0;
     return MI355PT_OK;

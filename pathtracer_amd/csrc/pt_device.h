@@ -227,9 +227,11 @@ PT_DEV bool slab_straight(const float* b, F3 p, F3 inv, float& tnear) {
 
 // Pruning guard.  The reference has no distance culling at all (bvh.h:88-129 ignores t); skipping a
 // subtree whose slab entry distance lies beyond the best hit is exact in real arithmetic, but the
-// triangle's t (plane equation, cancellation ~ eps * |o| / cos) and the slab's entry distance round
-// differently, so the cull keeps a margin far above either error: a subtree is skipped only when
-// tnear > bt * (1 + 1e-4) + 1e-4 * |o|_1.  Cost: a handful of extra node visits per thousand.
+// triangle's t (plane equation, cancellation ~ eps * (|v0| + |o|) / |cos|) and the slab's entry distance round
+// differently, so the cull keeps a margin: a subtree is skipped only when
+// tnear > (bt + E) * (1 + 1e-4) + 1e-4 * |o|_1, E = the largest error bound of the candidates accepted so far
+// (tri_closest_key).  What this covers and what it cannot (a culled triangle met at under ~0.3 degrees whose
+// neighbours were not): DESIGN.md "Distance cull".  MI355PT_NO_CULL=1 removes the cull for verification.
 PT_DEV float prune_abs(F3 o) { return 1e-4f * (fabsf(o.x) + fabsf(o.y) + fabsf(o.z)); }
 PT_DEV bool beyond(float tnear, float bt, float pabs) { return tnear > bt * 1.0001f + pabs; }
 
@@ -312,7 +314,11 @@ PT_DEV bool tri_closest(const Tri& T, F3 o, F3 d, int side, uint32_t slot, float
 }
 // The same test against a packed (t, slot) key (see hit_key in mi355pt.hip): returns true, and the candidate's key,
 // when the candidate is inside the triangle and strictly better than `cur`.
-PT_DEV bool tri_closest_key(const Tri& T, F3 o, F3 d, uint32_t slot, unsigned long long cur, unsigned long long& ck) {
+// `cerr` (set on acceptance): a bound on how far the computed distance can lie from the geometric one -- the two dot
+// products of the numerator cancel, so their rounding (and the rounding of n itself) is divided by |d . n|:
+// 2^-20 * (sum |v0_i n_i| + sum |o_i n_i|) / |d . n|  (about 16 half-ulps of the operands; a few ulp for an ordinary hit,
+// the whole distance for a ray that grazes the triangle's plane).
+PT_DEV bool tri_closest_key(const Tri& T, F3 o, F3 d, uint32_t slot, unsigned long long cur, unsigned long long& ck, float& cerr) {
     const F3 v01 = T.v1 - T.v0, v02 = T.v2 - T.v0;
     const F3 n = gcross(v01, v02);
     const float dn = gdot(d, n);
@@ -328,6 +334,7 @@ PT_DEV bool tri_closest_key(const Tri& T, F3 o, F3 d, uint32_t slot, unsigned lo
     if (a0 <= 0.0f) return false;
     if (a1 <= 0.0f) return false;
     if (a2 <= 0.0f) return false;
+    cerr = 9.5367431640625e-7f * ((fabsf(T.v0.x * n.x) + fabsf(T.v0.y * n.y) + fabsf(T.v0.z * n.z)) + (fabsf(o.x * n.x) + fabsf(o.y * n.y) + fabsf(o.z * n.z))) / fabsf(dn);
     return true;
 }
 // Any-hit form for visibility (raytracer.cpp:99-130): front faces only, accepted iff t < bound.

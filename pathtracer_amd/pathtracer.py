@@ -156,6 +156,16 @@ class PathTracer:
                                                          mesh.ctypes.data, face.ctypes.data, t.ctypes.data), "trace_rays")
         return node, mesh, face, t
 
+    def trace_visibility(self, origins, dirs, tmax, light=0):
+        """LightVisTest toward light `light` for arbitrary rays: uint8 array, 1 = blocked."""
+        origins = np.ascontiguousarray(origins, dtype=np.float32)
+        dirs = np.ascontiguousarray(dirs, dtype=np.float32)
+        tmax = np.ascontiguousarray(tmax, dtype=np.float32)
+        blocked = np.zeros(origins.shape[0], dtype=np.uint8)
+        capi.check(self.lib, self.lib.mi355pt_trace_visibility(self.h, origins.ctypes.data, dirs.ctypes.data, tmax.ctypes.data, int(light),
+                                                               origins.shape[0], blocked.ctypes.data), "trace_visibility")
+        return blocked
+
     def sample_radiance(self, pixel, sample):
         pixel = np.ascontiguousarray(pixel, dtype=np.uint32)
         sample = np.ascontiguousarray(sample, dtype=np.uint32)

@@ -20,7 +20,7 @@ from tests import common                         # noqa: E402
 
 SEED = 0x5EED
 GW, GH = 48, 32          # golden resolution (small: the file is committed)
-NPAIRS = 256
+NPAIRS = 2048
 
 
 def vectors(name):

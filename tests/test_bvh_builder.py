@@ -31,11 +31,31 @@ def check(mesh):
     return n
 
 
-@pytest.mark.parametrize("name,tris,nodes", [("teapot_lowpoly", 240, 201), ("cat", 2082, 2309), ("teapot", 6320, 6493)])
-def test_shipped_assets(name, tris, nodes):
+def tree_shape(nodes, n):
+    """(depth, largest leaf) of an exported pointer tree; the root is at depth 0."""
+    depth, max_leaf, stack = 0, 0, [(0, 0)]
+    while stack:
+        i, d = stack.pop()
+        depth = max(depth, d)
+        if nodes[i].left < 0:
+            max_leaf = max(max_leaf, nodes[i].face_count)
+        else:
+            stack += [(nodes[i].left, d + 1), (nodes[i].right, d + 1)]
+    return depth, max_leaf
+
+
+# Second-hand pins: the only recorded outputs of the REAL reference builder (SURVEY section 6, probe of MeshBVHNew on the
+# shipped assets): triangle count after import, node count, tree depth, largest leaf.  Both builders must reproduce them.
+@pytest.mark.parametrize("name,tris,nodes,depth,max_leaf", [("teapot_lowpoly", 240, 201, 8, 4), ("cat", 2082, 2309, 14, 6),
+                                                            ("teapot", 6320, 6493, 15, 7)])
+def test_shipped_assets(name, tris, nodes, depth, max_leaf):
     mesh = scene.load_obj(os.path.join(common.ASSETS, name + ".obj"))
     assert mesh.faces.shape[0] == tris          # face counts of the reference's assimp import (SURVEY 8c)
     assert check(mesh) == nodes
+    bn, _, n = capi.build_bvh(mesh)
+    assert tree_shape(bn, n) == (depth, max_leaf)
+    on, _ = oracle_bvh(mesh)
+    assert tree_shape(on, len(on)) == (depth, max_leaf)
 
 
 @pytest.mark.parametrize("ntris,seed", [(1, 1), (2, 2), (3, 3), (17, 4), (500, 5), (4000, 6)])

@@ -152,6 +152,82 @@ def test_errors_are_loud(built):
     import ctypes as C
     hnd = C.c_void_p()
     assert pt.lib.mi355pt_render_create(pt.dscene.h, C.byref(bad), C.byref(hnd)) == -1
+    # node.light / lights[].node must be in range and point at each other (the kernels index lights[] with node.light)
+    for what in ("node_light_range", "node_light_mismatch", "light_node_mismatch"):
+        desc, keep = s.to_desc()
+        li = [i for i in range(desc.num_nodes) if desc.nodes[i].light >= 0][0]
+        other = [i for i in range(desc.num_nodes) if desc.nodes[i].light < 0 and desc.nodes[i].object_kind != capi.OBJ_NONE][0]
+        if what == "node_light_range":
+            desc.nodes[li].light = desc.num_lights
+        elif what == "node_light_mismatch":
+            desc.nodes[other].light = 0
+        else:
+            desc.lights[0].node = other
+        hs = C.c_void_p()
+        assert pt.lib.mi355pt_scene_create(C.byref(desc), 0, C.byref(hs)) == -1, what
+        assert b"light" in pt.lib.mi355pt_last_error()
+
+
+def _pile_scene():
+    """A leaf of nine coincident triangles (cut into chain records) that a diagonal ray through the MESH-SPACE ORIGIN meets
+    before a second triangle; clutter gives the tree internal nodes.  One copy per octant."""
+    from pathtracer_amd import scene as sc
+    rng = np.random.default_rng(4)
+    tris = []
+    for sx in (-1, 1):
+        for sy in (-1, 1):
+            for sz in (-1, 1):
+                sg = np.array([sx, sy, sz], dtype=np.float64)
+                def plane_tri(c, r):          # a triangle of radius r around the diagonal point c * (1,1,1), in the plane perpendicular to it
+                    u = np.array([1, -1, 0]) / np.sqrt(2); v = np.array([1, 1, -2]) / np.sqrt(6)
+                    pts = [np.full(3, c) + r * (np.cos(a) * u + np.sin(a) * v) for a in (0.3, 2.4, 4.5)]
+                    return np.array(pts) * sg
+                for _ in range(9):
+                    tris.append(plane_tri(4.0, 1.5))              # the pile: t = 4 sqrt(3) from (8, 8, 8) * sg
+                tris.append(plane_tri(2.0, 1.5))                  # behind it: t = 6 sqrt(3); the origin is at t = 8 sqrt(3)
+                for _ in range(40):
+                    c = (rng.uniform(1.0, 9.0, 3)) * sg
+                    tris.append(c + rng.uniform(-0.3, 0.3, (3, 3)))
+    allt = np.array(tris, dtype=np.float32)
+    nt = allt.shape[0]
+    v = allt.reshape(-1, 3)
+    mesh = sc.Mesh(v, np.tile(np.array([[0, 0, 1]], dtype=np.float32), (3 * nt, 1)), np.zeros_like(v), np.arange(3 * nt, dtype=np.uint32).reshape(-1, 3))
+    s = sc.Scene()
+    m = sc.MtlDisney("m", albedo=(0.7, 0.7, 0.7), roughness=0.8)
+    s.materials = [m]
+    s.rootNode.AppendChild(sc.Node("pile", sc.Model([mesh]), m))
+    s.camera = sc.Camera((0, -30, 5), (0, 0, 0), (0, 0, 1), fov=40.0, width=16, height=16)
+    return s
+
+
+def test_chain_record_ray_through_mesh_origin():
+    """chain records carry no bound; a zero box there is `hit` by a diagonal ray through the mesh-space origin at
+    the origin's distance, and the distance cull then dropped the leaf's triangles when a nearer candidate was known.
+    Rays along (+-1, +-1, +-1) from (8, 8, 8) * sign, plus jittered neighbours, against the oracle."""
+    from oracle.binding import OracleScene
+    s = _pile_scene()
+    pt = PathTracer(s)
+    pt.Init(16, 16)
+    orc = OracleScene(s)
+    o, d = [], []
+    rng = np.random.default_rng(1)
+    for sx in (-1, 1):
+        for sy in (-1, 1):
+            for sz in (-1, 1):
+                sg = np.array([sx, sy, sz], dtype=np.float32)
+                dd = -sg / np.sqrt(np.float32(3.0))
+                o.append(sg * 8); d.append(dd)                                   # exactly through (0, 0, 0): equal slab distances on all axes
+                for _ in range(63):
+                    j = (dd + rng.normal(0, 0.02, 3).astype(np.float32)); j /= np.linalg.norm(j)
+                    o.append(sg * 8); d.append(j.astype(np.float32))
+    o, d = np.array(o, dtype=np.float32), np.array(d, dtype=np.float32)
+    node, mesh, face, t = pt.trace_rays(o, d)
+    onode, omesh, oface, ot = orc.trace_rays(o, d)
+    exact = np.arange(0, o.shape[0], 64)
+    assert (oface[exact] % 50 == 0).all(), "the reference meets the pile's first face on the exact diagonals"
+    assert np.array_equal(node, onode) and np.array_equal(face, oface)
+    assert np.array_equal(t.view(np.uint32), ot.view(np.uint32))
+    pt.close_render()
 
 
 @pytest.mark.parametrize("name", ["teapot_cornell", "grid_small", "textured_c2", "stress_layout"])
@@ -327,7 +403,7 @@ def test_against_committed_golden_vectors(name):
         assert np.all(np.abs(t - g[f"{name}/t"]) <= 1e-5 * np.abs(g[f"{name}/t"]))
     lin, mp = pt.sample_radiance(g[f"{name}/pixel"], g[f"{name}/sample"])
     frac, _ = common.radiance_agreement(lin, g[f"{name}/linear"])
-    assert frac >= 0.99, frac            # 256 pairs: allow 2 branch-flipped paths
+    assert frac >= 0.999, frac           # 2048 pairs, the same bar as against the live oracle
     pt.render(4)
     mean, cnt = pt.read_accum()
     assert common.rel_mse(mean, g[f"{name}/mean4"]) <= 1e-3
