@@ -313,6 +313,21 @@ int mi355pt_render_set_profiling(mi355pt_render* render, int enable_events, int 
  * back on one stream.  Results do not depend on it.  Takes effect at the next render_step. */
 int mi355pt_render_set_overlap(mi355pt_render* render, uint32_t from_bounce);
 
+/* No counterpart in the reference.  For callers that cannot allocate device memory -- code under HIP graph
+ * capture, tight serving loops, harnesses that forbid hipMalloc: TraceNode (src/raytracer.cpp:189-258,
+ * HIT_FRONT_AND_BACK) for `count` world-space rays like mi355pt_trace_rays, but with DEVICE pointers in and out
+ * (origins / dirs: 3 floats per ray; node / mesh / face / t: one value per ray), enqueued on the caller's
+ * `stream` (a hipStream_t; NULL = the null stream) and not synchronised, and with every byte of working memory
+ * (staged rays, hit records, the traversal kernel's work counter and stack spill area) in a static device array
+ * of about 12.6 MB that each GPU the library has created a scene on holds until the process ends.  It calls no
+ * hipMalloc / hipFree or any allocating routine, needs no renderer, and rejects count > MI355PT_STATIC_MAX_RAYS
+ * with MI355PT_ERR_TOO_LARGE.  All calls on one GPU share that GPU's array: calls that overlap on one GPU
+ * (different streams, or different host threads) race; serialise them on one stream.  A traversal that trips
+ * its internal pass guard poisons the outputs (ids -2, t = NaN) since no status can be read back without a copy. */
+#define MI355PT_STATIC_MAX_RAYS 131072u
+int mi355pt_trace_rays_static(mi355pt_scene* scene, const float* d_origins, const float* d_dirs, uint32_t count,
+                              int32_t* d_node, int32_t* d_mesh, int32_t* d_face, float* d_t, void* stream);
+
 /* The renderer's main stream (hipStream_t): every step begins and ends on it (the second stream's
  * work is joined into it before the step's last kernel), so an event recorded on it after
  * mi355pt_render_step, or a wait on it, orders against the whole step.                          */

@@ -104,8 +104,9 @@ SYMBOLS = [
     "mi355pt_render_read_rgb8", "mi355pt_render_read_accum", "mi355pt_render_write_accum",
     "mi355pt_render_accum_device_ptrs", "mi355pt_trace_primary", "mi355pt_trace_rays", "mi355pt_sample_radiance",
     "mi355pt_render_stats", "mi355pt_render_reset_stats", "mi355pt_render_set_profiling", "mi355pt_render_set_overlap", "mi355pt_render_stream",
-    "mi355pt_trace_visibility",
+    "mi355pt_trace_rays_static", "mi355pt_trace_visibility",
 ]
+STATIC_MAX_RAYS = 131072
 
 _lib = None
 
@@ -150,6 +151,7 @@ def load_library(path=None):
     lib.mi355pt_render_stream.argtypes = [vp]
     lib.mi355pt_render_stream.restype = vp
     lib.mi355pt_trace_visibility.argtypes = [vp, C.c_void_p, C.c_void_p, C.c_void_p, i32, u32, C.c_void_p]
+    lib.mi355pt_trace_rays_static.argtypes = [vp, vp, vp, u32, vp, vp, vp, vp, vp]
     if path is None:
         _lib = lib
     return lib

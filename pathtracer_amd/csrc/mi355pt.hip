@@ -1011,6 +1011,48 @@ __global__ void __launch_bounds__(kBlock) k_primary_out(DScene S, DPaths P, uint
     }
 }
 
+// ---------------------------------------------------------------------- the entry point that allocates nothing
+// mi355pt_trace_rays_static (include/mi355pt.h): TraceNode for a bounded batch of rays with ALL working memory -- the
+// staged 32-B rays, the 16-B hit records, the persistent kernel's work counter and guard word, the per-wave stack spill
+// area -- in one file-scope device array.  Every GPU the library runs on holds its own copy of the array at its own
+// address until the process ends; host code never uses the array's name as an address (it is a host-side stand-in):
+// scene_create asks the runtime for the device address once per device (hipGetSymbolAddress) and keeps it.
+constexpr uint32_t kStaticMaxRays = MI355PT_STATIC_MAX_RAYS;
+constexpr uint32_t kStaticWaves = 512;                                   // persistent waves of the static launch (spill area per wave)
+constexpr size_t kStaticRayOff = 0;                                      // float4[2 * max rays]
+constexpr size_t kStaticHitOff = kStaticRayOff + (size_t)kStaticMaxRays * 32;      // uint4[max rays]
+constexpr size_t kStaticCtrOff = kStaticHitOff + (size_t)kStaticMaxRays * 16;      // 256 B: work counter [0], stat[16] at +64
+constexpr size_t kStaticSpillOff = kStaticCtrOff + 256;                  // u32[waves][kStackSize][64]
+constexpr size_t kStaticBytes = kStaticSpillOff + (size_t)kStaticWaves * kStackSize * 64 * 4;
+static __device__ __align__(256) unsigned char scratch[kStaticBytes];
+
+__global__ void __launch_bounds__(kBlock) k_static_in(const float* origins, const float* dirs, uint32_t n, float4* ray) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        ray[2 * (size_t)i] = make_float4(origins[3 * (size_t)i], origins[3 * (size_t)i + 1], origins[3 * (size_t)i + 2], 0.0f);
+        ray[2 * (size_t)i + 1] = make_float4(dirs[3 * (size_t)i], dirs[3 * (size_t)i + 1], dirs[3 * (size_t)i + 2], 0.0f);
+    }
+}
+// k_primary_out for the static path: a tripped traversal guard cannot be reported through a status code without a
+// device-to-host copy, so it poisons the outputs instead (ids -2, t = NaN).
+__global__ void __launch_bounds__(kBlock) k_static_out(DScene S, DPaths P, uint32_t n, int32_t* node, int32_t* mesh, int32_t* face, float* t) {
+    const bool bad = P.stat[7] != 0ull;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const HitRec h = load_hit(P, i);
+        if (bad) { node[i] = -2; mesh[i] = -2; face[i] = -2; t[i] = __uint_as_float(0x7FC00000u); continue; }
+        t[i] = h.t;
+        if (h.inst < 0) { node[i] = -1; mesh[i] = -1; face[i] = -1; }
+        else {
+            const DInst& in = S.insts[h.inst];
+            node[i] = in.node; mesh[i] = h.mesh; face[i] = -1;
+            if (in.kind == MI355PT_OBJ_MODEL) {
+                const DMesh& M = S.meshes[S.models[in.model].first_mesh + h.mesh];
+                const Tri T = load_tri(S.tris, h.slot);
+                face[i] = (int32_t)S.faces[4 * (size_t)(M.face_base + T.face) + 3];
+            }
+        }
+    }
+}
+
 // ====================================================================== host side
 namespace {
 
@@ -1040,8 +1082,15 @@ float h_len(H3 a) { return sqrtf(a.x * a.x + a.y * a.y + a.z * a.z); }
 
 }  // namespace
 
+// device address of `scratch` on each device, taken once with that device current (hipGetSymbolAddress)
+constexpr int kMaxDevices = 64;
+static std::mutex g_scratch_mu;
+static unsigned char* g_scratch_ptr[kMaxDevices] = {nullptr};
+
 struct mi355pt_scene {
     int device = 0;
+    unsigned char* static_scratch = nullptr;     // this device's copy of `scratch`
+    uint32_t static_entries = 16; size_t static_lds = 0;
     DScene d{};
     mi355pt_camera camera{};
     std::vector<ptb::MeshTree> trees;
@@ -1401,6 +1450,19 @@ int mi355pt_scene_create(const mi355pt_scene_desc* desc, int32_t device, mi355pt
         x = rr * sinf(y * (float)M_PI * 2);
         y = rr * cosf(y * (float)M_PI * 2);
         d.filter_taps[2 * i] = x; d.filter_taps[2 * i + 1] = y;
+    }
+    {   // set-up of mi355pt_trace_rays_static for this device: the address of this GPU's copy of the static array
+        if (device >= kMaxDevices) return fail(MI355PT_ERR_TOO_LARGE, "device ordinal beyond the static scratch table");
+        std::lock_guard<std::mutex> g(g_scratch_mu);
+        if (!g_scratch_ptr[device]) {
+            unsigned char* ptr = nullptr;
+            HIP_TRY(hipGetSymbolAddress((void**)&ptr, HIP_SYMBOL(scratch)));
+            if (!ptr) return fail(MI355PT_ERR_HIP, "hipGetSymbolAddress(scratch) returned a null address");
+            g_scratch_ptr[device] = ptr;
+        }
+        sc->static_scratch = g_scratch_ptr[device];
+        sc->static_entries = std::max(8, sc->max_depth + 3) <= 8 ? 8u : 16u;
+        sc->static_lds = extend_lds_bytes(sc->static_entries);
     }
     *out = sc.release();
     return MI355PT_OK;
@@ -1886,6 +1948,32 @@ int mi355pt_sample_radiance(mi355pt_render* r, const uint32_t* pixel, const uint
     if (e == hipSuccess && linear_rgb) e = hipMemcpy(linear_rgb, dl, (size_t)count * 12, hipMemcpyDeviceToHost);
     if (e == hipSuccess && mapped_rgb) e = hipMemcpy(mapped_rgb, dm, (size_t)count * 12, hipMemcpyDeviceToHost);
     HIP_TRY(e);
+    return MI355PT_OK;
+}
+
+int mi355pt_trace_rays_static(mi355pt_scene* scene, const float* d_origins, const float* d_dirs, uint32_t count,
+                              int32_t* d_node, int32_t* d_mesh, int32_t* d_face, float* d_t, void* stream) {
+    if (!scene || !d_origins || !d_dirs || !d_node || !d_mesh || !d_face || !d_t) return fail(MI355PT_ERR_INVALID, "null argument");
+    if (count == 0) return MI355PT_OK;
+    if (count > kStaticMaxRays) return fail(MI355PT_ERR_TOO_LARGE, "more rays than MI355PT_STATIC_MAX_RAYS (the static scratch array holds that many)");
+    if (!scene->static_scratch) return fail(MI355PT_ERR_HIP, "static scratch address not set up");
+    HIP_TRY(hipSetDevice(scene->device));
+    hipStream_t st = (hipStream_t)stream;
+    unsigned char* base = scene->static_scratch;            // never the array's name: that is a host-side stand-in
+    DPaths P{};
+    P.cap = kStaticMaxRays;
+    P.ray = (float4*)(base + kStaticRayOff); P.hit = (uint4*)(base + kStaticHitOff);
+    P.work = (uint32_t*)(base + kStaticCtrOff); P.stat = (unsigned long long*)(base + kStaticCtrOff + 64);
+    P.spill = (uint32_t*)(base + kStaticSpillOff);
+    // the array keeps the last call's contents: the work counter and the guard word must start at zero
+    HIP_TRY(hipMemsetAsync(base + kStaticCtrOff, 0, 256, st));
+    Params prm{0u, 1u, 1u, 1u, 0u, scene->static_entries, kNodeLanes, 64u, 0u, 0u};
+    const int g = (int)std::max<size_t>(1, std::min<size_t>(((size_t)count + kBlock - 1) / kBlock, 2048));
+    const int ge = (int)std::max<size_t>(1, std::min<size_t>(((size_t)count + 63) / 64, kStaticWaves));
+    hipLaunchKernelGGL(k_static_in, dim3(g), dim3(kBlock), 0, st, d_origins, d_dirs, count, P.ray);
+    hipLaunchKernelGGL((k_trace<0, false>), dim3(ge), dim3(kExtBlock), scene->static_lds, st, scene->d, P, prm, 0u, count);
+    hipLaunchKernelGGL(k_static_out, dim3(g), dim3(kBlock), 0, st, scene->d, P, count, d_node, d_mesh, d_face, d_t);
+    HIP_TRY(hipGetLastError());
     return MI355PT_OK;
 }
 
