@@ -4,7 +4,7 @@
 Workload (BASELINE.json configs[3], the 10M-triangle scene the metric is quoted on): the
 instanced teapot_lowpoly grid baked into one 10 036 800-triangle mesh / one BVH, 3840x2160,
 Disney rough material + one rectangular area light, primary + secondary rays, 30 bounces max.
-One "step" = one sample per pixel of the whole frame through the full hot path
+One "step" = one batch of --spp-per-step (default 8) samples per pixel of the whole frame through the full hot path
 (init -> {extend, shade, connect} x bounces -> resolve) with the scene resident in HBM.
 
 N GPUs: one process per GPU (torch.distributed, backend nccl == RCCL); the scene is replicated and
@@ -94,6 +94,8 @@ def main():
     ap.add_argument("--cpu-crop", type=int, nargs=2, default=[3840, 2160])
     ap.add_argument("--cpu-spp", type=int, default=3)
     ap.add_argument("--split", choices=["sample", "tile"], default="sample")
+    ap.add_argument("--spp-per-step", type=int, default=8,
+                    help="samples per pixel in one step = one batch through the hot path (the late bounces' fixed cost is paid once per batch)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -123,11 +125,11 @@ def main():
     if args.split == "tile":
         ts, toff, tstride = distributed.rank_tile_split(rank, world, 64)
         pt = PathTracer(scene, device=device, seed=args.seed, tile_size=ts, tile_offset=toff, tile_stride=tstride)
-        spp_step = world            # a rank owns 1/N of the pixels: N samples of each keep the per-GPU work fixed
+        spp_step = world * args.spp_per_step        # a rank owns 1/N of the pixels: N samples of each keep the per-GPU work fixed
     else:
         off, stride = distributed.rank_sample_split(rank, world)
         pt = PathTracer(scene, device=device, seed=args.seed, sample_offset=off, sample_stride=stride)
-        spp_step = 1
+        spp_step = args.spp_per_step
     pt.Init(args.width, args.height)
     if rank == 0:
         log(f"scene + BVH + upload: {time.perf_counter() - t0:.1f} s")
@@ -175,10 +177,11 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": workload, "triangles": int(pt.dscene.desc.meshes[0].num_faces) if pt.dscene.desc.num_meshes else 0,
-                       "resolution": [args.width, args.height], "spp_per_step": 1, "max_bounces": 30,
+                       "resolution": [args.width, args.height], "spp_per_step": args.spp_per_step, "max_bounces": 30,
                        "split": ("sample index g, g+N, ... per GPU" if args.split == "sample" else "64x64 image tiles k % N == g, N spp per step")
                                 + "; one RCCL reduce at the end"},
             "samples_per_pixel_per_s": samples_total / npix / dt,
+            "ms_per_sample": dt / args.steps / args.spp_per_step * 1e3,
             "rays_per_sample": rays_total / max(samples_total, 1.0),
         }
     # ---- roofline of the dominant kernel (k_trace<closest>, the extend stage): algorithmic bytes / measured launch time

@@ -291,19 +291,30 @@ void flatten_tree(const MeshTree& t, FlatMesh& out) {
             } else { st.push_back(s.left); st.push_back(s.right); }   // right popped first
         }
     }
-    // 2. internal-node records in left-first pre-order
+    // 2. internal-node records: the top of the tree first, breadth-first (the first kTopRecords internal nodes: every ray
+    //    starts there, and k_trace keeps as many of these records as fit in LDS -- a contiguous index range, closed towards the
+    //    root), then the rest in left-first pre-order
     std::vector<int> rec(nn, -1);
     int nrec = 0;
-    {
+    if (t.nodes[0].left >= 0) {
+        std::vector<int> bfs; bfs.push_back(0);
+        for (size_t h = 0; h < bfs.size() && nrec < (int)kTopRecords; h++) {
+            const int n = bfs[h];
+            rec[n] = nrec++;
+            const TmpNode& s = t.nodes[n];
+            if (t.nodes[s.left].left >= 0) bfs.push_back(s.left);
+            if (t.nodes[s.right].left >= 0) bfs.push_back(s.right);
+        }
         std::vector<int> st; st.push_back(0);
         while (!st.empty()) {
             int n = st.back(); st.pop_back();
             const TmpNode& s = t.nodes[n];
             if (s.left < 0) continue;
-            rec[n] = nrec++;
+            if (rec[n] < 0) rec[n] = nrec++;
             st.push_back(s.right); st.push_back(s.left);
         }
     }
+    out.top_records = (uint32_t)std::min<int>(nrec, (int)kTopRecords);
     out.node_words.assign(16 * (size_t)nrec, 0.0f);
     auto put_u = [&](size_t w, uint32_t v) { memcpy(&out.node_words[w], &v, 4); };
     // A leaf of more than kMaxLeaf triangles becomes a chain of bound-less records (count word kChain):

@@ -49,9 +49,11 @@ struct FlatMesh {
     std::vector<float>    node_words;   // 16 words per internal node (bit-cast uints in words 12..15)
     std::vector<uint32_t> slot_face;    // triangle slot -> position in the mesh's faces[] array
     uint32_t root_ref = 0, root_cnt = 0;
+    uint32_t top_records = 0;           // records [0, top_records) are the top of the tree in breadth-first order
     int      max_depth = 0;
 };
 constexpr uint32_t kInternal = 0xFFFFFFFFu, kChain = 0xFFFFFFFEu, kMaxLeaf = 4;
+constexpr uint32_t kTopRecords = 255;   // breadth-first prefix of the record order (the top 8 levels of a full tree)
 void flatten_tree(const MeshTree& t, FlatMesh& out);
 
 }  // namespace ptb

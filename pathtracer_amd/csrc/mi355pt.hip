@@ -65,7 +65,7 @@ struct DPaths {
     uint32_t *spill_any;  // the same for k_trace<ANY>, which may run beside k_trace<closest> of the next bounce
     unsigned long long *stat;   // [0] closest rays [1] shadow rays [2] samples [3,4] extend node visits / tri tests [5,6] visibility ditto [7] guard
 };
-struct Params { uint32_t seed, width, height, max_bounces, rr_start, stack_entries, node_lanes, owner_lanes, gen, use_prep, no_cull; };
+struct Params { uint32_t seed, width, height, max_bounces, rr_start, stack_entries, node_lanes, owner_lanes, gen, use_prep, no_cull, ntop; };
 
 __device__ __forceinline__ F3 xyz(float4 v) { return f3(v.x, v.y, v.z); }
 __device__ __forceinline__ float4 f4(F3 v, float w) { return make_float4(v.x, v.y, v.z, w); }
@@ -211,7 +211,14 @@ __global__ void __launch_bounds__(kBlock) k_raygen(DCamera cam, DPaths P, Params
 // None of this changes results: the winner is the minimum over the same triangle set in (t, slot) order
 // (slot order == the reference's tie-break order, bvh_build.h), whoever tested which triangle when.
 enum { LS_IDLE = 0, LS_SETUP, LS_TRAV, LS_WAIT, LS_THIEF, LS_DONE };
-constexpr int kExtBlock = 64;
+constexpr int kExtBlockMax = 1024;      // k_trace: up to 16 waves per workgroup (MI355PT_WAVES_PER_WG), chosen at renderer creation
+// ordering point for one wave's LDS traffic: a wave's LDS instructions execute in order, so what one lane wrote the others see
+// once the compiler may not move accesses across this point; waves of a workgroup never wait for each other
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 constexpr uint32_t kLeafQ = 256;         // leaf items per wave; a node step needs room for 2 x 64
 constexpr uint32_t kNodeLanes = 24;      // the node loop yields when fewer lanes than this can take a step (MI355PT_NODE_LANES)
 constexpr uint32_t kMaxLeaf = ptb::kMaxLeaf;
@@ -221,10 +228,21 @@ static_assert(kMaxLeaf == 4, "leaf items carry count-1 in 2 bits and the triangl
 // LDS of one wave, in dwords, after the stack of `E` entries x 64 lanes
 constexpr uint32_t kRecCache = 3;        // walk records kept in LDS (a scene of a few objects is walked without touching memory)
 constexpr uint32_t kLdsQRef = 0, kLdsQOwn = kLdsQRef + kLeafQ, kLdsRay = kLdsQOwn + kLeafQ / 4, kLdsKey = kLdsRay + 64 * 8,
-                   kLdsWork = kLdsKey + 64 * 2, kLdsXfer = kLdsWork + 64, kLdsTri = kLdsXfer + 128, kLdsRec = kLdsTri + 64,
-                   kLdsEnd = kLdsRec + kRecCache * kRecStride * 4;
-static_assert((kLdsRay % 4) == 0 && (kLdsKey % 2) == 0 && (kLdsRec % 4) == 0, "alignment of the float4 / u64 parts");
-inline size_t extend_lds_bytes(uint32_t entries) { return ((size_t)entries * 64 + kLdsEnd) * 4; }
+                   kLdsWork = kLdsKey + 64 * 2, kLdsXfer = kLdsWork + 64, kLdsTri = kLdsXfer + 128, kLdsEnd = kLdsTri + 64;
+static_assert((kLdsRay % 4) == 0 && (kLdsKey % 2) == 0 && (kLdsEnd % 4) == 0, "alignment of the float4 / u64 parts");
+constexpr size_t kLdsPerCU = 163840;      // 160 KiB (MI355X_MICROARCH.md)
+constexpr size_t kLdsShared = (size_t)kRecCache * kRecStride * 16;         // per workgroup: the walk-record cache, then the BVH top
+inline size_t extend_lds_wave_bytes(uint32_t entries) { return ((size_t)entries * 64 + kLdsEnd) * 4; }
+// The launch shape of k_trace for a scene: waves per workgroup, how many of the BVH's top records its LDS holds, LDS bytes.
+struct TraceShape { uint32_t wpb, ntop; size_t lds; };
+inline TraceShape trace_shape(uint32_t entries, uint32_t wpb, uint32_t top_count) {
+    const size_t wg_budget = kLdsPerCU / (16u / wpb);                      // 16 waves per CU in all
+    const size_t fixed = wpb * extend_lds_wave_bytes(entries) + kLdsShared;
+    TraceShape t; t.wpb = wpb;
+    t.ntop = fixed < wg_budget ? (uint32_t)std::min<size_t>(top_count, (wg_budget - fixed) / 64) : 0u;
+    t.lds = fixed + (size_t)t.ntop * 64;
+    return t;
+}
 
 // (t, slot) as one ordered 64-bit key.  Accepted distances are >= 0 or -0.0 (the reference rejects only t < 0 and
 // compares the two zeros equal): both zeros map to the same high word, the sign is kept in bit 0 so that the
@@ -261,16 +279,20 @@ __global__ void __launch_bounds__(kBlock) k_prepare(DScene S, DPaths P, uint32_t
 // the closest hit, both sides, on the light's own object only, written to P.lhit for MODE 1 and k_connect -- the same
 // walk as MODE 0 over the light's records.  Plane and Sphere lights are tested analytically in MODE 1's set-up.
 template <int MODE, bool COUNT>
-__global__ void __launch_bounds__(kExtBlock) k_trace(DScene S, DPaths P, Params prm, uint32_t bounce, uint32_t n0) {
+__global__ void __launch_bounds__(kExtBlockMax) k_trace(DScene S, DPaths P, Params prm, uint32_t bounce, uint32_t n0) {
     constexpr bool ANY = MODE == 1, OWN = MODE == 2;
     const uint32_t n = MODE ? (uint32_t)(P.svcounts[bounce] >> 32) : (bounce == 0 ? n0 : P.counts[bounce]);
     const uint32_t* q = MODE ? P.vqueue : (bounce == 0 ? nullptr : P.queue[bounce & 1]);
     uint32_t* work = OWN ? &P.lwork[bounce] : ANY ? &P.vwork[bounce] : &P.work[bounce];
     extern __shared__ uint32_t sm[];
-    const uint32_t lane = threadIdx.x;
+    // A workgroup is `wpb` waves that never synchronise with each other after the set-up barrier: each wave is a persistent
+    // worker with its own LDS area; the workgroup exists to SHARE one LDS copy of the walk records and of the top of the BVH.
+    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6, wpb = blockDim.x >> 6;
+    const uint32_t wave_id = blockIdx.x * wpb + wv;
     const unsigned long long lt = (1ull << lane) - 1ull;
-    uint32_t* stk = sm;                                          // [E][64]
-    uint32_t* aux = sm + prm.stack_entries * 64;
+    const uint32_t per_wave = prm.stack_entries * 64u + kLdsEnd;
+    uint32_t* stk = sm + wv * per_wave;                          // [E][64]
+    uint32_t* aux = stk + prm.stack_entries * 64;
     uint32_t* qref = aux + kLdsQRef; uint8_t* qown = (uint8_t*)(aux + kLdsQOwn);
     float4* rayl = (float4*)(aux + kLdsRay);                     // [64][2]: (o, -), (d, -) of the owner's ray in mesh space
     unsigned long long* keyl = (unsigned long long*)(aux + kLdsKey);   // [64] best (t, slot) of the owner's current mesh
@@ -282,22 +304,28 @@ __global__ void __launch_bounds__(kExtBlock) k_trace(DScene S, DPaths P, Params 
     // compute for its coplanar neighbours in other subtrees: the distance cull must keep that far behind the best.
     // It lives in the spare word of the owner's ray record (rayl[2 * owner + 1].w).
 #define PT_MARG(ow) (((uint32_t*)rayl)[8u * (ow) + 7u])
+    // the two verification knobs act where the cull's terms are set, not in the node step: MI355PT_NO_CULL (no_cull == 1) makes
+    // the limit infinite -- the walk of the reference; MI355PT_CULL_PLAIN (2) drops the candidates' error bound (round 1's cull)
+    auto cull_abs = [&](F3 p) { return prm.no_cull == 1u ? __uint_as_float(0x7F800000u) : prune_abs(p); };
+    auto cull_marg = [&](uint32_t ow) { return (ANY || prm.no_cull == 2u) ? 0.0f : __uint_as_float(PT_MARG(ow)); };
     // A lane's traversal stack is logical entries [sb, sp); the top `stack_entries` (a power of two) of them live in an
     // LDS ring, entries below `lo` in the wave's spill area in global memory.  Depth-first, near-child-first walks keep a
     // stack of about one entry per level with both children hit: the window is rarely left, and a 16-entry window instead
     // of a full-depth stack is what lets 16 instead of 12 waves share a CU's LDS.
     const uint32_t rmask = prm.stack_entries - 1u;
-    uint32_t* spill = (MODE ? P.spill_any : P.spill) + (size_t)blockIdx.x * kStackSize * 64;
+    uint32_t* spill = (MODE ? P.spill_any : P.spill) + (size_t)wave_id * kStackSize * 64;
 #define PT_STK(i) stk[((i) & rmask) * 64 + lane]
 #define PT_SPILL(i) spill[(i) * 64 + lane]
-    WorkCounters wc; wc.nodes = 0; wc.tris = 0;
+    WorkCounters wc; wc.nodes = 0; wc.tris = 0; wc.top = 0;
     uint32_t state = LS_IDLE, slot = 0, rec = 0, sp = 0, sb = 0, lo = 0, owner = lane;
     F3 o = f3(0, 0, 0), inv = f3(0, 0, 0);
     float bt = kBig, pabs = 0.0f, bmarg = 0.0f;
+    bool fastok = false;                                                                  // this lane's ray may take slab_pair_fast
     float best_t = kBig; int best_inst = -1, best_mesh = -1; uint32_t best_slot = 0;      // closest: best over the objects so far
     float bound = 0.0f; uint32_t linst = 0;                                                // any: distance bound, the light's object
     uint32_t rec_end = (uint32_t)S.num_recs;                                               // own: end of the light's records
-    float4* recl = (float4*)(aux + kLdsRec);
+    float4* recl = (float4*)(sm + wpb * per_wave);                                      // shared by the workgroup: walk records ...
+    const float4* topl = recl + kRecCache * kRecStride;                                    // ... and the first prm.ntop BVH records
     // the ray of an item, already taken into the root node's space (level 0 of every object's chain)
     auto load_world = [&](uint32_t it, Ray& wr) {                // closest: `it` is a path slot; any: slot * 2 + which
         if (MODE == 0) {
@@ -309,7 +337,7 @@ __global__ void __launch_bounds__(kExtBlock) k_trace(DScene S, DPaths P, Params 
         if (S.num_recs > 0) wr = rec_ray(S, recl, 1u, 0u, wr);   // record 0 is cached in LDS; its level 0 is the root node
     };
     uint32_t qh = 0, nq = 0;                                     // leaf queue (ring): head, count -- wave-uniform
-    const uint32_t nwaves = gridDim.x;
+    const uint32_t nwaves = gridDim.x * wpb;
     // Queue chunk per atomic: up to 1024 rays while there is plenty of work per wave.  A short queue (the late bounces:
     // a few thousand surviving paths) is dealt out a few rays per wave and pass instead, so that every CU gets some
     // and the lanes without a ray of their own walk stolen subtrees of those few -- the launch is then bounded by
@@ -317,13 +345,18 @@ __global__ void __launch_bounds__(kExtBlock) k_trace(DScene S, DPaths P, Params 
     uint32_t chunk = (n / (8u * nwaves)) & ~63u; chunk = chunk < 64u ? 64u : (chunk > 1024u ? 1024u : chunk);
     const bool trickle = n < 64u * nwaves;
     if (trickle) { chunk = (n + nwaves - 1u) / nwaves; chunk = chunk < 4u ? 4u : chunk; }
-    if (MODE == 0 && blockIdx.x == 0 && lane == 0 && P.progress) {
+    if (MODE == 0 && wave_id == 0 && lane == 0 && P.progress) {
         __hip_atomic_store(&P.progress[bounce], ((unsigned long long)prm.gen << 32) | (unsigned long long)(n + 1u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
-    if (blockIdx.x * chunk >= n) return;                         // nothing left for this wave even on the first deal
+    if (blockIdx.x * wpb * chunk >= n) return;                   // nothing for any wave of this workgroup even on the first deal
     const uint32_t ncache = (uint32_t)S.num_recs < kRecCache ? (uint32_t)S.num_recs : kRecCache;
-    for (uint32_t i = lane; i < ncache * kRecStride; i += 64u) recl[i] = S.recs[i];
-    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < ncache * kRecStride; i += blockDim.x) recl[i] = S.recs[i];
+    // The top of the largest mesh's BVH (records top_base .. top_base + ntop, breadth-first: bvh_build.cpp): every ray starts
+    // there, and a record read from LDS is a record the CU's vector-memory path does not serve -- that path, at about one
+    // 16-B access per cycle and CU, is what bounds this kernel.
+    for (uint32_t i = threadIdx.x; i < prm.ntop * 4u; i += blockDim.x) ((float4*)topl)[i] = S.bvh_nodes[4 * (size_t)S.top_base + i];
+    __syncthreads();                                             // the workgroup's only barrier
+    if (wave_id * chunk >= n) return;                            // nothing left for this wave
     uint32_t pool_next = 0, pool_end = 0; bool exhausted = false;
     uint32_t guard = 0;
     // counting builds: wave cycles per phase, passes, node-loop lanes (stats.debug, tools/diag_bounces.py)
@@ -426,7 +459,7 @@ __global__ void __launch_bounds__(kExtBlock) k_trace(DScene S, DPaths P, Params 
                     keyl[lane] = ANY ? 0ull : hit_key(best_t, 0u) & ~1ull;       // any: 1 = blocked
                     owner = lane; sb = 0; lo = 0;
                     if (root_cnt >= kChain) {
-                        o = lp; inv = linv; pabs = prune_abs(lp); bt = ANY ? bound : best_t; bmarg = ANY ? 0.0f : __uint_as_float(PT_MARG(lane));
+                        o = lp; inv = linv; fastok = slab_fast_ok(lp, linv); pabs = cull_abs(lp); bt = ANY ? bound : best_t; bmarg = cull_marg(lane);
                         PT_STK(0) = root_ref; sp = 1; nwork[lane] = 1; state = LS_TRAV;
                     } else {
                         root_leaf = kLeafFlag | ((root_cnt - 1u) << 27) | root_ref;
@@ -495,84 +528,86 @@ __global__ void __launch_bounds__(kExtBlock) k_trace(DScene S, DPaths P, Params 
         }
         PT_PHASE(ck_setup);
         if (__ballot(state != LS_DONE) == 0) break;
-        __syncthreads();
+        wave_sync();
         // ================= node steps, while most lanes can take one
+        // The step is written for instruction count -- the kernel is bound by instruction issue, not by memory:
+        //  * a record's two control words are ready-made: > 0 the record index of a node child (internal, or a chain record,
+        //    whose box in its parent is [-inf, +inf]: always entered), < 0 the leaf-queue item of a leaf child, 0 nothing;
+        //  * the cull limit is constant during a node phase (candidates are only tested at the drain) and computed once;
+        //  * the stack window is made safe for one pop and two pushes BEFORE the step, for the whole wave, in a branch that is
+        //    rarely taken, so the step itself pops and pushes without checks and writes both push slots unconditionally
+        //    (a word above the top of the stack is dead);
+        //  * rays whose 1/d and origin are finite and non-zero take the min/max form of the slab test, which gives the
+        //    reference's values and verdicts exactly for them (pt_device.h, slab_pair_fast); a wave with any other ray on a
+        //    step takes the reference's literal form.
         {
-            const uint32_t ntrav = (uint32_t)__popcll(__ballot(state == LS_TRAV || state == LS_THIEF));
+            const uint32_t ntrav = (uint32_t)__popcll(__ballot(sp != sb));
             uint32_t th = (3u * ntrav + 3u) / 4u; th = th > prm.node_lanes ? prm.node_lanes : th;
             // with many lanes free to steal, come back to the steal phase after a couple of steps: work doubles per pass
             const uint32_t nfree = (uint32_t)__popcll(__ballot(state == LS_DONE || (trickle && state == LS_IDLE)));
             const uint32_t max_it = nfree >= 16u ? 2u : 0xFFFFFFFFu;
+            const float lim = (bt + bmarg) * 1.0001f + pabs;          // conservative distance cull (pt_device.h, prune_abs)
             uint32_t it = 0;
             bool first = true;
             for (;;) {
-                const bool want = (state == LS_TRAV || state == LS_THIEF) && sp > sb;
-                const uint32_t nw = (uint32_t)__popcll(__ballot(want));
+                const bool want = sp != sb;                             // only lanes in LS_TRAV / LS_THIEF have entries
+                const unsigned long long wm = __ballot(want);
+                const uint32_t nw = (uint32_t)__popcll(wm);
                 if (nw == 0 || (!first && nw < th) || kLeafQ - nq < 128u || it >= max_it) break;
                 first = false; it++;
                 if (COUNT) { n_node_it++; n_node_act += nw; }
-                uint32_t leafL = 0, leafR = 0;
+                // window: the top entry in LDS, room for two more above it
+                if (__ballot(want && (sp - 1u < lo || sp + 1u > lo + prm.stack_entries))) {
+                    if (want) {
+                        if (sp - 1u < lo) { lo = sp - 1u; PT_STK(lo) = PT_SPILL(lo); }      // the window was empty: the top entry comes back
+                        while (sp + 1u > lo + prm.stack_entries) { PT_SPILL(lo) = PT_STK(lo); lo++; }
+                    }
+                }
+                const bool wave_fast = __ballot(want && !fastok) == 0ull;
+                int fL = 0, fR = 0;                                       // leaf items of this step (negative) or 0
+#ifdef PT_PROBE_SALU      // cost-model probes (tools/ab_bench.sh): 32 extra scalar / vector instructions per node step
+                { uint32_t t_ = it; asm volatile(".rept 32\n\ts_add_u32 %0, %0, 1\n\t.endr" : "+s"(t_)); if (t_ == 0xFFFFFFFFu) break; }
+#endif
+#ifdef PT_PROBE_VALU
+                { uint32_t t_ = sp; asm volatile(".rept 32\n\tv_add_u32 %0, %0, 1\n\t.endr" : "+v"(t_)); if (__ballot(t_ == 0xFFFFFFFFu) == ~0ull) break; }
+#endif
                 if (want) {
                     sp--;
-                    uint32_t e;
-                    if (sp >= lo) e = PT_STK(sp);
-                    else { e = PT_SPILL(sp); lo = sp; }                  // the window is empty: the next entry comes back from the spill area
+                    const uint32_t e = PT_STK(sp);
+                    const uint32_t te = e - S.top_base;               // < ntop: the record is in LDS
                     const float4* np = S.bvh_nodes + 4 * (size_t)e;
-                    const float4 w0 = np[0], w1 = np[1], w2 = np[2], w3 = np[3];
+                    float4 w0, w1, w2, w3;
+                    if (te < prm.ntop) { const float4* tp = topl + 4 * te; w0 = tp[0]; w1 = tp[1]; w2 = tp[2]; w3 = tp[3]; if (COUNT) wc.top++; }
+                    else { w0 = np[0]; w1 = np[1]; w2 = np[2]; w3 = np[3]; }
                     if (COUNT) wc.nodes++;
-                    const uint32_t lref = __float_as_uint(w3.x), rref = __float_as_uint(w3.y), lcnt = __float_as_uint(w3.z), rcnt = __float_as_uint(w3.w);
-                    // both child slabs, always (bvh.h:88-129 with 1/dir hoisted; same values)
-                    const bool s0 = inv.x < 0, s1 = inv.y < 0, s2 = inv.z < 0;
+#ifdef PT_PROBE_LOADS     // cost-model probe: the record's four 16-B pieces fetched a second time (L1 hits): does the number of accesses matter?
+                    { float4 t0_, t1_, t2_, t3_;
+                      asm volatile("global_load_dwordx4 %0, %4, off\n\tglobal_load_dwordx4 %1, %4, off offset:16\n\tglobal_load_dwordx4 %2, %4, off offset:32\n\tglobal_load_dwordx4 %3, %4, off offset:48\n\ts_waitcnt vmcnt(0)"
+                                   : "=&v"(t0_), "=&v"(t1_), "=&v"(t2_), "=&v"(t3_) : "v"(np) : "memory");
+                      if (t0_.x + t1_.y + t2_.z + t3_.w == 1.2345e-30f) sp++; }
+#endif
                     float tl, tr; bool hl, hr;
-                    {
-                        float tmin = ((s0 ? w0.w : w0.x) - o.x) * inv.x, tmax = ((s0 ? w0.x : w0.w) - o.x) * inv.x;
-                        const float tymin = ((s1 ? w1.x : w0.y) - o.y) * inv.y, tymax = ((s1 ? w0.y : w1.x) - o.y) * inv.y;
-                        bool ok = !((tmin > tymax) || (tymin > tmax));
-                        if (tymin > tmin) tmin = tymin;
-                        if (tymax < tmax) tmax = tymax;
-                        const float tzmin = ((s2 ? w1.y : w0.z) - o.z) * inv.z, tzmax = ((s2 ? w0.z : w1.y) - o.z) * inv.z;
-                        ok = ok && !((tmin > tzmax) || (tzmin > tmax));
-                        if (tzmin > tmin) tmin = tzmin;
-                        hl = ok; tl = tmin;
-                    }
-                    {
-                        float tmin = ((s0 ? w2.y : w1.z) - o.x) * inv.x, tmax = ((s0 ? w1.z : w2.y) - o.x) * inv.x;
-                        const float tymin = ((s1 ? w2.z : w1.w) - o.y) * inv.y, tymax = ((s1 ? w1.w : w2.z) - o.y) * inv.y;
-                        bool ok = !((tmin > tymax) || (tymin > tmax));
-                        if (tymin > tmin) tmin = tymin;
-                        if (tymax < tmax) tmax = tymax;
-                        const float tzmin = ((s2 ? w2.w : w2.x) - o.z) * inv.z, tzmax = ((s2 ? w2.x : w2.w) - o.z) * inv.z;
-                        ok = ok && !((tmin > tzmax) || (tzmin > tmax));
-                        if (tzmin > tmin) tmin = tzmin;
-                        hr = ok; tr = tmin;
-                    }
-                    // conservative distance cull (pt_device.h, prune_abs); MI355PT_NO_CULL walks like the reference, with none
-                    // (no_cull == 2, MI355PT_CULL_PLAIN: round 1's cull without the candidates' error bound -- kept so that a test can
-                    // show the adversarial rays do break it)
-                    const float lim = prm.no_cull == 1u ? __uint_as_float(0x7F800000u) : (bt + (prm.no_cull == 2u ? 0.0f : bmarg)) * 1.0001f + pabs;
-                    const bool farL = hl & (tl > lim), farR = hr & (tr > lim);
-                    // internal children: entered iff their slab is hit (and not culled); chain records always
-                    const bool pushL = (lcnt == kChain) | ((lcnt == kInternal) & hl & !farL);
-                    const bool pushR = (rcnt == kChain) | ((rcnt == kInternal) & hr & !farR);
+                    if (wave_fast) slab_pair_fast(w0, w1, w2, o, inv, hl, tl, hr, tr);
+                    else slab_pair_exact(w0, w1, w2, o, inv, hl, tl, hr, tr);       // bvh.h:88-129 with 1/dir hoisted; same values
+                    const int CL = __float_as_int(w3.x), CR = __float_as_int(w3.y);
+                    const bool nearL = !(tl > lim), nearR = !(tr > lim);
+                    // node children: entered iff their slab is hit and not beyond the limit
+                    const int nL = max((hl & nearL) ? CL : 0, 0), nR = max((hr & nearR) ? CR : 0, 0);
                     // leaf children: the reference tests no leaf bound (model.cpp:6-25), so a leaf whose slab is MISSED is
-                    // still tested; one whose slab is hit beyond the current best is culled like an internal child
-                    if ((lcnt - 1u < kMaxLeaf) & !farL) leafL = kLeafFlag | ((lcnt - 1u) << 27) | lref;
-                    if ((rcnt - 1u < kMaxLeaf) & !farR) leafR = kLeafFlag | ((rcnt - 1u) << 27) | rref;
+                    // still tested; one whose slab is hit beyond the limit is culled like a node child
+                    fL = min((!hl | nearL) ? CL : 0, 0); fR = min((!hr | nearR) ? CR : 0, 0);
                     // near child on top
-                    const bool rnear = pushL & pushR & (tr < tl);
-                    const uint32_t e0 = pushL ? (rnear ? lref : (pushR ? rref : lref)) : rref;    // deeper entry (far child, or the only one)
-                    const uint32_t e1 = rnear ? rref : lref;                                      // top entry when both are pushed
-                    const uint32_t npush = (pushL ? 1u : 0u) + (pushR ? 1u : 0u);
-                    while (sp + npush > lo + prm.stack_entries) { PT_SPILL(lo) = PT_STK(lo); lo++; }      // make room in the window (at most twice)
-                    if (pushL | pushR) PT_STK(sp) = e0;
-                    if (pushL & pushR) PT_STK(sp + 1) = e1;
-                    sp += npush;
+                    const bool swp = tr < tl;
+                    const uint32_t deep = (uint32_t)(swp ? nL : nR), top = (uint32_t)(swp ? nR : nL);
+                    PT_STK(sp) = deep ? deep : top;
+                    PT_STK(sp + 1u) = top;
+                    sp += (deep ? 1u : 0u) + (top ? 1u : 0u);
                 }
-                const unsigned long long mL = __ballot(leafL != 0u), mR = __ballot(leafR != 0u);
+                const unsigned long long mL = __ballot(fL != 0), mR = __ballot(fR != 0);
                 if (mL | mR) {
                     const uint32_t cL = (uint32_t)__popcll(mL);
-                    if (leafL) { const uint32_t pos = (qh + nq + (uint32_t)__popcll(mL & lt)) % kLeafQ; qref[pos] = leafL; qown[pos] = (uint8_t)owner; }
-                    if (leafR) { const uint32_t pos = (qh + nq + cL + (uint32_t)__popcll(mR & lt)) % kLeafQ; qref[pos] = leafR; qown[pos] = (uint8_t)owner; }
+                    if (fL) { const uint32_t pos = (qh + nq + (uint32_t)__popcll(mL & lt)) % kLeafQ; qref[pos] = (uint32_t)fL; qown[pos] = (uint8_t)owner; }
+                    if (fR) { const uint32_t pos = (qh + nq + cL + (uint32_t)__popcll(mR & lt)) % kLeafQ; qref[pos] = (uint32_t)fR; qown[pos] = (uint8_t)owner; }
                     nq += cL + (uint32_t)__popcll(mR);
                 }
                 if (want && sp == sb) {                               // this lane's share of the ray is walked
@@ -581,7 +616,7 @@ __global__ void __launch_bounds__(kExtBlock) k_trace(DScene S, DPaths P, Params 
                 }
             }
         }
-        __syncthreads();
+        wave_sync();
         PT_PHASE(ck_node);
         // ================= drain the leaf queue: one triangle per lane per pass, whatever ray it belongs to
         while (nq > 0) {
@@ -593,7 +628,7 @@ __global__ void __launch_bounds__(kExtBlock) k_trace(DScene S, DPaths P, Params 
             const uint32_t pre = (uint32_t)__popcll(b0 & lt) + 2u * (uint32_t)__popcll(b1 & lt) + lane;
             const uint32_t total = (uint32_t)__popcll(b0) + 2u * (uint32_t)__popcll(b1) + m;
             if (has) for (uint32_t k = 0; k <= c1; k++) tril[pre + k] = (uint8_t)((lane << 2) | k);
-            __syncthreads();
+            wave_sync();
             // two triangles per lane and pass: both fetches are in flight before either test runs
             for (uint32_t base = 0; base < total; base += 128u) {
                 if (COUNT) { const uint32_t left = total - base; n_drain_it += left > 64u ? 2u : 1u; n_drain_act += left < 128u ? left : 128u; }
@@ -626,17 +661,17 @@ __global__ void __launch_bounds__(kExtBlock) k_trace(DScene S, DPaths P, Params 
                     }
                 }
             }
-            __syncthreads();
+            wave_sync();
             qh = (qh + m) % kLeafQ; nq -= m;
         }
         PT_PHASE(ck_drain);
         // ================= after the drain: refresh pruning distances, finish meshes, steal
         if (state == LS_TRAV || state == LS_THIEF) {
             const unsigned long long k = keyl[owner];
-            if (!ANY) { bt = __uint_as_float((uint32_t)(k >> 32)); bmarg = __uint_as_float(PT_MARG(owner)); }
+            if (!ANY) { bt = __uint_as_float((uint32_t)(k >> 32)); bmarg = cull_marg(owner); }
             else if (k) { sp = sb; lo = sb; atomicSub(&nwork[owner], 1u); state = state == LS_TRAV ? LS_WAIT : (exhausted ? LS_DONE : LS_IDLE); }   // blocked: abandon the walk
         }
-        __syncthreads();
+        wave_sync();
         if (state == LS_WAIT && nwork[lane] == 0u) {                    // every lane that walked for this ray is done, the queue is empty
             const unsigned long long k = keyl[lane];
             if (ANY) {
@@ -669,18 +704,18 @@ __global__ void __launch_bounds__(kExtBlock) k_trace(DScene S, DPaths P, Params 
                     const uint32_t r = (uint32_t)__popcll(donors & lt);
                     if (r < k) { xfer[r] = sb >= lo ? PT_STK(sb) : PT_SPILL(sb); xfer[64 + r] = owner; sb++; lo = lo < sb ? sb : lo; atomicAdd(&nwork[owner], 1u); }
                 }
-                __syncthreads();
+                wave_sync();
                 if (free_lane) {
                     const uint32_t r = (uint32_t)__popcll(idle & lt);
                     if (r < k) {
                         owner = xfer[64 + r];
                         const float4 ro = rayl[2 * owner], rd = rayl[2 * owner + 1];
-                        o = f3(ro.x, ro.y, ro.z); inv = f3(1.0f, 1.0f, 1.0f) / f3(rd.x, rd.y, rd.z); pabs = prune_abs(o);
-                        bt = ANY ? ro.w : __uint_as_float((uint32_t)(keyl[owner] >> 32)); bmarg = ANY ? 0.0f : __uint_as_float(PT_MARG(owner));
+                        o = f3(ro.x, ro.y, ro.z); inv = f3(1.0f, 1.0f, 1.0f) / f3(rd.x, rd.y, rd.z); fastok = slab_fast_ok(o, inv); pabs = cull_abs(o);
+                        bt = ANY ? ro.w : __uint_as_float((uint32_t)(keyl[owner] >> 32)); bmarg = cull_marg(owner);
                         PT_STK(0) = xfer[r]; sp = 1; sb = 0; lo = 0; state = LS_THIEF;
                     }
                 }
-                __syncthreads();
+                wave_sync();
             }
         }
         PT_PHASE(ck_rest);
@@ -689,7 +724,7 @@ __global__ void __launch_bounds__(kExtBlock) k_trace(DScene S, DPaths P, Params 
 #undef PT_MARG
 #undef PT_SPILL
 #undef PT_PHASE
-    if (COUNT) { wave_add64(wc.nodes, &P.stat[MODE ? 5 : 3]); wave_add64(wc.tris, &P.stat[MODE ? 6 : 4]);
+    if (COUNT) { wave_add64(wc.nodes, &P.stat[MODE ? 5 : 3]); wave_add64(wc.tris, &P.stat[MODE ? 6 : 4]); if (MODE == 0) wave_add64(wc.top, &P.stat[15]);
         if (MODE == 0 && lane == 0) { atomicAdd(&P.stat[8], ck_setup); atomicAdd(&P.stat[9], ck_node); atomicAdd(&P.stat[10], ck_drain); atomicAdd(&P.stat[11], ck_rest);
                                  atomicAdd(&P.stat[12], n_node_it); atomicAdd(&P.stat[13], n_node_act); atomicAdd(&P.stat[14], (n_drain_it << 32) | 0ull); } 
         if (MODE == 0 && lane == 0) atomicAdd(&P.stat[14], n_drain_act); }
@@ -1090,7 +1125,7 @@ static unsigned char* g_scratch_ptr[kMaxDevices] = {nullptr};
 struct mi355pt_scene {
     int device = 0;
     unsigned char* static_scratch = nullptr;     // this device's copy of `scratch`
-    uint32_t static_entries = 16; size_t static_lds = 0;
+    uint32_t static_entries = 16; TraceShape static_shape{1, 0, 0};
     DScene d{};
     mi355pt_camera camera{};
     std::vector<ptb::MeshTree> trees;
@@ -1141,7 +1176,7 @@ struct mi355pt_render {
     struct Ev { hipEvent_t a, b; int kind; };
     std::vector<Ev> events; bool ev_open = false;
     double ms[4] = {0, 0, 0, 0}; uint64_t extend_launches = 0;
-    int grid = 2048, extend_grid = 768; size_t extend_lds = 0; uint32_t stack_entries = 8, node_lanes = kNodeLanes, owner_lanes = 64;
+    int grid = 2048, extend_grid = 768; TraceShape shape{1, 0, 0}; uint32_t stack_entries = 8, node_lanes = kNodeLanes, owner_lanes = 64;
     ~mi355pt_render() {
         for (auto& e : events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
         for (hipEvent_t e : fork) (void)hipEventDestroy(e);
@@ -1165,6 +1200,23 @@ int check_device(int device) {
     if (std::string(p.gcnArchName).find("gfx950") == std::string::npos)
         return fail(MI355PT_ERR_NO_DEVICE, std::string("device is ") + p.gcnArchName + ", this library is built for gfx950 only");
     return MI355PT_OK;
+}
+
+// k_trace's workgroups may ask for more than the default 64 KB of dynamic LDS (several waves' areas plus the shared BVH top)
+int allow_large_lds() {
+    const int lim = (int)kLdsPerCU;
+    HIP_TRY(hipFuncSetAttribute((const void*)k_trace<0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
+    HIP_TRY(hipFuncSetAttribute((const void*)k_trace<0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
+    HIP_TRY(hipFuncSetAttribute((const void*)k_trace<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
+    HIP_TRY(hipFuncSetAttribute((const void*)k_trace<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
+    HIP_TRY(hipFuncSetAttribute((const void*)k_trace<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
+    HIP_TRY(hipFuncSetAttribute((const void*)k_trace<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
+    return MI355PT_OK;
+}
+uint32_t waves_per_workgroup() {
+    uint32_t w = 4;
+    if (const char* e = getenv("MI355PT_WAVES_PER_WG")) w = (uint32_t)atoi(e);
+    return (w == 1 || w == 2 || w == 4 || w == 8 || w == 16) ? w : 4u;
 }
 
 DCamera init_camera(const mi355pt_camera& c, uint32_t w, uint32_t h) {      // InitCamera, raytracer.cpp:318-333
@@ -1303,6 +1355,7 @@ int mi355pt_scene_create(const mi355pt_scene_desc* desc, int32_t device, mi355pt
     std::vector<float4> bvh_nodes, tris, attrs;
     std::vector<uint32_t> faces; std::vector<float> normals, uvw, tangents, bitangents;
     sc->trees.resize(desc->num_meshes);
+    uint32_t top_base = 0, top_count = 0, top_faces = 0;      // the BVH top k_trace keeps in LDS: that of the mesh with most triangles
     const int threads = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
     for (uint32_t mi = 0; mi < desc->num_meshes; mi++) {
         const mi355pt_mesh& s = desc->meshes[mi];
@@ -1325,6 +1378,7 @@ int mi355pt_scene_create(const mi355pt_scene_desc* desc, int32_t device, mi355pt
         if ((uint64_t)tri_base + flat.slot_face.size() > (uint64_t)kLeafSlotMask) return fail(MI355PT_ERR_TOO_LARGE, "more than 2^27 triangles");
         d.face_base = (uint32_t)(faces.size() / 4); d.vert_base = (uint32_t)(normals.size() / 3);
         d.has_tangents = (s.tangents && s.bitangents) ? 1 : 0; d.pad = 0;
+        if (flat.top_records > 0 && s.num_faces > top_faces) { top_faces = s.num_faces; top_base = node_base; top_count = flat.top_records; }
         const bool root_internal = flat.root_cnt >= ptb::kChain;
         d.root_ref = root_internal ? node_base : tri_base + flat.root_ref; d.root_cnt = flat.root_cnt;
         // node records: rebase references to the global pools
@@ -1332,8 +1386,20 @@ int mi355pt_scene_create(const mi355pt_scene_desc* desc, int32_t device, mi355pt
         bvh_nodes.resize(bvh_nodes.size() + 4 * nrec);
         for (size_t r = 0; r < nrec; r++) {
             float w[16]; memcpy(w, &flat.node_words[16 * r], sizeof(w));
+            // the device form of the two children (k_trace's node step): word 12 / 13 = record index of a node child (> 0;
+            // a chain record's box becomes [-inf, +inf]: entered whatever the ray), or the ready-made leaf-queue item of a
+            // leaf child (bit 31 set), or 0 for a leaf without triangles; words 14 / 15 unused
             uint32_t u[4]; memcpy(u, &w[12], sizeof(u));
-            for (int c = 0; c < 2; c++) u[c] += (u[2 + c] >= ptb::kChain) ? node_base : tri_base;
+            for (int c = 0; c < 2; c++) {
+                const uint32_t cnt = u[2 + c];
+                if (cnt >= ptb::kChain) {
+                    u[c] += node_base;
+                    if (u[c] == 0u || u[c] >= 0x80000000u) return fail(MI355PT_ERR_TOO_LARGE, "node record index out of range");
+                    if (cnt == ptb::kChain) for (int a = 0; a < 3; a++) { w[6 * c + a] = -INFINITY; w[6 * c + 3 + a] = INFINITY; }
+                } else if (cnt == 0u) u[c] = 0u;
+                else u[c] = kLeafFlag | ((cnt - 1u) << 27) | (u[c] + tri_base);
+            }
+            u[2] = u[3] = 0u;
             memcpy(&w[12], u, sizeof(u));
             memcpy(&bvh_nodes[4 * ((size_t)node_base + r)], w, sizeof(w));
         }
@@ -1442,6 +1508,7 @@ int mi355pt_scene_create(const mi355pt_scene_desc* desc, int32_t device, mi355pt
     d.plane_lights_only = 1;
     for (const DLight& L : lights) if (L.kind != MI355PT_OBJ_PLANE) d.plane_lights_only = 0;
     d.recs = sc->recs.p; d.num_recs = (int)(recs.size() / kRecStride);
+    d.top_base = top_base; d.top_count = top_count;
     memcpy(d.env_color, desc->env_color, sizeof(d.env_color)); d.env_map = desc->env_map;
     for (int i = 0; i < 32; i++) {      // Texture::Sample tap offsets (scene.h:169-175), host libm like the reference
         auto halton = [](int index, int base) { float r = 0; float f = 1.0f / (float)base; for (int k = index; k > 0; k /= base) { r += f * (k % base); f /= (float)base; } return r; };
@@ -1462,7 +1529,8 @@ int mi355pt_scene_create(const mi355pt_scene_desc* desc, int32_t device, mi355pt
         }
         sc->static_scratch = g_scratch_ptr[device];
         sc->static_entries = std::max(8, sc->max_depth + 3) <= 8 ? 8u : 16u;
-        sc->static_lds = extend_lds_bytes(sc->static_entries);
+        sc->static_shape = trace_shape(sc->static_entries, waves_per_workgroup(), top_count);
+        if (int rc = allow_large_lds()) return rc;
     }
     *out = sc.release();
     return MI355PT_OK;
@@ -1533,7 +1601,10 @@ int mi355pt_render_create(mi355pt_scene* scene, const mi355pt_render_params* par
     r->overlap_from = 0;
     if (const char* e = getenv("MI355PT_OVERLAP_FROM")) r->overlap_from = (uint32_t)std::max(0, atoi(e));
     const size_t npix = (size_t)params->width * params->height;
-    size_t cap = 8388608;
+    // Path slots of one chunk.  Eight samples of a 4K frame fit (294 B per slot, 19.7 GB): a step of several samples runs them as ONE batch, and the fixed
+    // cost of a batch -- above all the ~20 late bounces that a few thousand Russian-roulette survivors drag out at one ray's
+    // latency each (3.4 of 18 ms for a single 4K sample of C4, profiles/r02b_timeline.txt) -- is paid once per batch.
+    size_t cap = 67108864;
     if (const char* e = getenv("MI355PT_MAX_PATHS")) cap = std::max<size_t>(65536, strtoull(e, nullptr, 10));
     cap = std::min(cap, std::max<size_t>(npix, 65536) * 64);
     cap = (cap + 63) & ~(size_t)63;
@@ -1600,11 +1671,14 @@ int mi355pt_render_create(mi355pt_scene* scene, const mi355pt_render_params* par
         int entries = need <= 8 ? 8 : 16;                              // LDS window (power of two); deeper entries spill to P.spill
         if (const char* e = getenv("MI355PT_STACK_WINDOW")) entries = atoi(e) <= 4 ? 4 : (atoi(e) <= 8 ? 8 : 16);     // test knob: a small window spills all the time
         r->stack_entries = (uint32_t)entries;
-        r->extend_lds = extend_lds_bytes((uint32_t)entries);
-        int waves = 0;
-        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&waves, k_trace<0, false>, kExtBlock, r->extend_lds));
-        if (const char* e = getenv("MI355PT_EXTEND_WAVES_PER_CU")) waves = std::min(waves, std::max(1, atoi(e)));
-        r->extend_grid = prop.multiProcessorCount * std::max(1, waves);
+        // workgroups of several waves share one LDS copy of the walk records and of the BVH's top records (as many as fit beside
+        // 16 waves' own areas); MI355PT_NO_TOP keeps none (A/B knob), MI355PT_WAVES_PER_WG sets the workgroup size
+        r->shape = trace_shape((uint32_t)entries, waves_per_workgroup(), getenv("MI355PT_NO_TOP") ? 0u : scene->d.top_count);
+        int blocks = 0;
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, k_trace<0, false>, (int)r->shape.wpb * 64, r->shape.lds));
+        int waves = std::max(1, blocks) * (int)r->shape.wpb;
+        if (const char* e = getenv("MI355PT_EXTEND_WAVES_PER_CU")) waves = std::max((int)r->shape.wpb, std::min(waves, atoi(e)) / (int)r->shape.wpb * (int)r->shape.wpb);
+        r->extend_grid = prop.multiProcessorCount * waves;
         HIP_TRY(dalloc((void**)&P.spill, (size_t)r->extend_grid * kStackSize * 64 * 4));
         HIP_TRY(dalloc((void**)&P.spill_any, (size_t)r->extend_grid * kStackSize * 64 * 4));
     }
@@ -1618,7 +1692,7 @@ int mi355pt_render_create(mi355pt_scene* scene, const mi355pt_render_params* par
         memset(r->progress, 0, nb * sizeof(unsigned long long));
         HIP_TRY(hipHostGetDevicePointer((void**)&P.progress, r->progress, 0));
     }
-    if (getenv("MI355PT_VERBOSE")) fprintf(stderr, "mi355pt: tree depth %d, extend grid %d waves, LDS %zu B/wave\n", scene->max_depth, r->extend_grid, r->extend_lds);
+    if (getenv("MI355PT_VERBOSE")) fprintf(stderr, "mi355pt: tree depth %d, extend grid %d waves in workgroups of %u, LDS %zu B per workgroup, %u of %u top BVH records in LDS\n", scene->max_depth, r->extend_grid, r->shape.wpb, r->shape.lds, r->shape.ntop, scene->d.top_count);
     { std::lock_guard<std::mutex> g(scene->life); scene->renderers++; }
     *out = r.release();
     return MI355PT_OK;
@@ -1653,6 +1727,15 @@ int ensure_hook(mi355pt_render* r, size_t bytes) {
 }
 #define PT_LOCK(r) std::lock_guard<std::recursive_mutex> lk_((r)->mu)
 
+// One launch of the traversal kernel on `nwaves` persistent waves in workgroups of sh.wpb.
+template <int MODE>
+void launch_trace(bool count, size_t nwaves, const TraceShape& sh, hipStream_t st, const DScene& S, const DPaths& P, Params prm, uint32_t bounce, uint32_t n) {
+    prm.ntop = sh.ntop;
+    const dim3 grid((unsigned)((nwaves + sh.wpb - 1) / sh.wpb)), block(sh.wpb * 64u);
+    if (count) hipLaunchKernelGGL((k_trace<MODE, true>), grid, block, sh.lds, st, S, P, prm, bounce, n);
+    else hipLaunchKernelGGL((k_trace<MODE, false>), grid, block, sh.lds, st, S, P, prm, bounce, n);
+}
+
 int grid_for(const mi355pt_render* r, size_t n) {
     size_t b = (n + kBlock - 1) / kBlock;
     return (int)std::max<size_t>(1, std::min<size_t>(b, (size_t)r->grid));
@@ -1681,7 +1764,10 @@ void drain_events(mi355pt_render* r) {
 
 // The bounce loop for `n` initialised path slots.
 bool use_prepass(const mi355pt_render* r, uint32_t n) {
-    return !r->count_work && r->prep_bounces > 0 && r->scene->num_tris > 0 && n >= r->prep_min_paths;
+    // (counting builds count the walk's root-bound visits in the kernel, so they run without the pre-pass -- unless a diagnostic
+    // asks for the production schedule's phase split: MI355PT_COUNT_WITH_PREP)
+    static const bool count_with_prep = getenv("MI355PT_COUNT_WITH_PREP") != nullptr;
+    return (!r->count_work || count_with_prep) && r->prep_bounces > 0 && r->scene->num_tris > 0 && n >= r->prep_min_paths;
 }
 
 int run_paths(mi355pt_render* r, uint32_t n, uint32_t jitter = 1, uint32_t only_extend = 0, bool prep0_done = false) {
@@ -1701,8 +1787,7 @@ int run_paths(mi355pt_render* r, uint32_t n, uint32_t jitter = 1, uint32_t only_
         pb.use_prep = (b < r->prep_bounces && use_prepass(r, n)) ? 1u : 0u;
         if (pb.use_prep && !(b == 0 && prep0_done)) hipLaunchKernelGGL(k_prepare, dim3(g), dim3(kBlock), 0, r->stream, S, P, b, n);
         ev_begin(r, 0, r->stream);
-        if (r->count_work) hipLaunchKernelGGL((k_trace<0, true>), dim3(ge), dim3(kExtBlock), r->extend_lds, r->stream, S, P, pb, b, n);
-        else hipLaunchKernelGGL((k_trace<0, false>), dim3(ge), dim3(kExtBlock), r->extend_lds, r->stream, S, P, pb, b, n);
+        launch_trace<0>(r->count_work, (size_t)ge, r->shape, r->stream, S, P, pb, b, n);
         ev_end(r, r->stream);
     };
     const uint32_t nbounce = only_extend ? 0u : p.max_bounces;
@@ -1739,11 +1824,9 @@ int run_paths(mi355pt_render* r, uint32_t n, uint32_t jitter = 1, uint32_t only_
         }
         ev_begin(r, 2, vs);
         if (r->scene->model_lights) {                       // lights on Models: their own-object sweep first
-            if (r->count_work) hipLaunchKernelGGL((k_trace<2, true>), dim3(ge), dim3(kExtBlock), r->extend_lds, vs, S, P, prm, b, n);
-            else hipLaunchKernelGGL((k_trace<2, false>), dim3(ge), dim3(kExtBlock), r->extend_lds, vs, S, P, prm, b, n);
+            launch_trace<2>(r->count_work, (size_t)ge, r->shape, vs, S, P, prm, b, n);
         }
-        if (r->count_work) hipLaunchKernelGGL((k_trace<1, true>), dim3(ge), dim3(kExtBlock), r->extend_lds, vs, S, P, prm, b, n);
-        else hipLaunchKernelGGL((k_trace<1, false>), dim3(ge), dim3(kExtBlock), r->extend_lds, vs, S, P, prm, b, n);
+        launch_trace<1>(r->count_work, (size_t)ge, r->shape, vs, S, P, prm, b, n);
         hipLaunchKernelGGL(k_connect, dim3(g), dim3(kBlock), 0, vs, S, P, b);
         ev_end(r, vs);
         if (fork) { HIP_TRY(hipEventRecord(r->join[b], vs)); pending = true; last_fork = b; }
@@ -1914,8 +1997,8 @@ int mi355pt_trace_visibility(mi355pt_render* r, const float* origins, const floa
     Params prm{p.seed, p.width, p.height, p.max_bounces, p.rr_start, r->stack_entries, r->node_lanes, r->owner_lanes, ++r->gen, 0u, r->no_cull};
     const int ge = (int)std::max<size_t>(1, std::min<size_t>((n + 63) / 64, (size_t)r->extend_grid));
     const DScene& S = r->scene->d;
-    if (r->scene->model_lights) hipLaunchKernelGGL((k_trace<2, false>), dim3(ge), dim3(kExtBlock), r->extend_lds, r->stream, S, r->P, prm, 0u, count);
-    hipLaunchKernelGGL((k_trace<1, false>), dim3(ge), dim3(kExtBlock), r->extend_lds, r->stream, S, r->P, prm, 0u, count);
+    if (r->scene->model_lights) launch_trace<2>(false, (size_t)ge, r->shape, r->stream, S, r->P, prm, 0u, count);
+    launch_trace<1>(false, (size_t)ge, r->shape, r->stream, S, r->P, prm, 0u, count);
     HIP_TRY(hipGetLastError());
     if (int rc = mi355pt_render_sync(r)) return rc;
     std::vector<uint8_t> vis(2 * n);
@@ -1971,7 +2054,7 @@ int mi355pt_trace_rays_static(mi355pt_scene* scene, const float* d_origins, cons
     const int g = (int)std::max<size_t>(1, std::min<size_t>(((size_t)count + kBlock - 1) / kBlock, 2048));
     const int ge = (int)std::max<size_t>(1, std::min<size_t>(((size_t)count + 63) / 64, kStaticWaves));
     hipLaunchKernelGGL(k_static_in, dim3(g), dim3(kBlock), 0, st, d_origins, d_dirs, count, P.ray);
-    hipLaunchKernelGGL((k_trace<0, false>), dim3(ge), dim3(kExtBlock), scene->static_lds, st, scene->d, P, prm, 0u, count);
+    launch_trace<0>(false, (size_t)ge, scene->static_shape, st, scene->d, P, prm, 0u, count);
     hipLaunchKernelGGL(k_static_out, dim3(g), dim3(kBlock), 0, st, scene->d, P, count, d_node, d_mesh, d_face, d_t);
     HIP_TRY(hipGetLastError());
     return MI355PT_OK;

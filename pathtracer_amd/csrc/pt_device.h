@@ -225,6 +225,58 @@ PT_DEV bool slab_straight(const float* b, F3 p, F3 inv, float& tnear) {
     return ok;
 }
 
+// Both child boxes of a 64-B node record (w0.xyzw w1.xy = left min/max, w1.zw w2.xyzw = right min/max), the reference's
+// literal form: sign-selected planes, sequential interval tests, NaN comparisons fall through as "hit" (bvh.h:95-129).
+PT_DEV void slab_pair_exact(float4 w0, float4 w1, float4 w2, F3 o, F3 inv, bool& hl, float& tl, bool& hr, float& tr) {
+    const bool s0 = inv.x < 0, s1 = inv.y < 0, s2 = inv.z < 0;
+    {
+        float tmin = ((s0 ? w0.w : w0.x) - o.x) * inv.x, tmax = ((s0 ? w0.x : w0.w) - o.x) * inv.x;
+        const float tymin = ((s1 ? w1.x : w0.y) - o.y) * inv.y, tymax = ((s1 ? w0.y : w1.x) - o.y) * inv.y;
+        bool ok = !((tmin > tymax) || (tymin > tmax));
+        if (tymin > tmin) tmin = tymin;
+        if (tymax < tmax) tmax = tymax;
+        const float tzmin = ((s2 ? w1.y : w0.z) - o.z) * inv.z, tzmax = ((s2 ? w0.z : w1.y) - o.z) * inv.z;
+        ok = ok && !((tmin > tzmax) || (tzmin > tmax));
+        if (tzmin > tmin) tmin = tzmin;
+        hl = ok; tl = tmin;
+    }
+    {
+        float tmin = ((s0 ? w2.y : w1.z) - o.x) * inv.x, tmax = ((s0 ? w1.z : w2.y) - o.x) * inv.x;
+        const float tymin = ((s1 ? w2.z : w1.w) - o.y) * inv.y, tymax = ((s1 ? w1.w : w2.z) - o.y) * inv.y;
+        bool ok = !((tmin > tymax) || (tymin > tmax));
+        if (tymin > tmin) tmin = tymin;
+        if (tymax < tmax) tmax = tymax;
+        const float tzmin = ((s2 ? w2.w : w2.x) - o.z) * inv.z, tzmax = ((s2 ? w2.x : w2.w) - o.z) * inv.z;
+        ok = ok && !((tmin > tzmax) || (tzmin > tmax));
+        if (tzmin > tmin) tmin = tzmin;
+        hr = ok; tr = tmin;
+    }
+}
+// The same test for a ray whose 1/d components are finite and non-zero and whose origin is finite (slab_fast_ok), without the
+// sign selects and the sequential tests.  For such a ray no product below is NaN (box planes are finite, or all NaN in a chain
+// record: then "not hit", which the caller treats like the literal form's "hit, never beyond" -- chain records have no internal
+// children).  Rounding is monotone, so for 1/d > 0 the lower plane gives the smaller product and for 1/d < 0 the larger: min / max
+// of the two products ARE the reference's sign-selected tmin / tmax, bit for bit.  Each axis interval is then non-empty, three
+// non-empty intervals have a common point iff they meet pairwise (the reference's two-stage test), i.e. iff
+// max(mins) <= min(maxs), and the reference's final tmin is max(mins) (equal up to the sign of a zero, which no use of it sees).
+PT_DEV void slab_one_fast(float x0, float y0, float z0, float x1, float y1, float z1, F3 o, F3 inv, bool& hit, float& tn) {
+    const float ax = (x0 - o.x) * inv.x, bx = (x1 - o.x) * inv.x;
+    const float ay = (y0 - o.y) * inv.y, by = (y1 - o.y) * inv.y;
+    const float az = (z0 - o.z) * inv.z, bz = (z1 - o.z) * inv.z;
+    const float tnear = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz));
+    const float tfar = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
+    hit = tnear <= tfar; tn = tnear;
+}
+PT_DEV void slab_pair_fast(float4 w0, float4 w1, float4 w2, F3 o, F3 inv, bool& hl, float& tl, bool& hr, float& tr) {
+    slab_one_fast(w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, o, inv, hl, tl);
+    slab_one_fast(w1.z, w1.w, w2.x, w2.y, w2.z, w2.w, o, inv, hr, tr);
+}
+PT_DEV bool slab_fast_ok(F3 o, F3 inv) {
+    const float big = __uint_as_float(0x7F800000u);
+    return fabsf(inv.x) < big && fabsf(inv.y) < big && fabsf(inv.z) < big && inv.x != 0.0f && inv.y != 0.0f && inv.z != 0.0f &&
+           fabsf(o.x) < big && fabsf(o.y) < big && fabsf(o.z) < big;
+}
+
 // Pruning guard.  The reference has no distance culling at all (bvh.h:88-129 ignores t); skipping a
 // subtree whose slab entry distance lies beyond the best hit is exact in real arithmetic, but the
 // triangle's t (plane equation, cancellation ~ eps * (|v0| + |o|) / |cos|) and the slab's entry distance round
@@ -358,7 +410,7 @@ constexpr int kStackSize = 48;        // stack entries per lane; the host checks
 constexpr int kTravBlock = 256;       // threads per block of the streaming kernels
 constexpr uint32_t kLeafFlag = 0x80000000u, kLeafSlotMask = 0x07FFFFFFu;   // leaf item: flag | (count - 1) << 27 | first slot
 constexpr uint32_t kInternal = 0xFFFFFFFFu, kChain = 0xFFFFFFFEu;         // count words of a node record
-struct WorkCounters { uint32_t nodes, tris; };
+struct WorkCounters { uint32_t nodes, tris, top; };
 struct HitRec { float t; int inst; int mesh; uint32_t slot; };     // closest-hit record of one path
 
 // ------------------------------------------------------------------ plane (objects.cpp:560-614)

@@ -52,6 +52,7 @@ struct DScene {
     const DModel*   models;
     const DMesh*    meshes;
     const float4*   bvh_nodes;       // 4 x float4 (64 B) per internal node, all meshes
+    uint32_t        top_base, top_count;   // records [top_base, top_base + top_count): the top of the largest mesh's tree, breadth-first
     const float4*   tris;            // 3 x float4 (48 B) per triangle slot: v0 v1 v2 faceId
     const float4*   attrs;           // 5 x float4 (80 B) per triangle slot: the three vertex normals (9 floats), then the three uvw (9)
     const uint32_t* faces;           // 4 per face: i0 i1 i2 faceId (mesh-local vertex indices)
