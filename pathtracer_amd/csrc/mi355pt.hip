@@ -741,7 +741,15 @@ constexpr int kShadeBlock = 64;
 #ifndef PT_SHADE_WAVES
 #define PT_SHADE_WAVES 2
 #endif
-__global__ void __launch_bounds__(kShadeBlock) __attribute__((amdgpu_waves_per_eu(PT_SHADE_WAVES, 8))) k_shade(DScene S, DCamera cam, DPaths P, Params prm, uint32_t bounce, uint32_t n0) {
+#ifndef PT_SHADE_WAVES_STD
+#define PT_SHADE_WAVES_STD 2
+#endif
+// KIND: the material model this instance shades (MI355PT_MTL_DISNEY / _STANDARD: two code bodies, disneyMaterial.h:85-203 and
+// standardMaterial.h:33-103): hits on the other kind are left to the other instance's launch, and only the instance with
+// `do_miss` finishes the misses.  A scene with one kind of material runs one instance.
+template <int KIND>
+__global__ void __launch_bounds__(kShadeBlock) __attribute__((amdgpu_waves_per_eu(KIND == MI355PT_MTL_STANDARD ? PT_SHADE_WAVES_STD : PT_SHADE_WAVES, 8)))
+k_shade(DScene S, DCamera cam, DPaths P, Params prm, uint32_t bounce, uint32_t n0, uint32_t do_miss) {
     const uint32_t n = bounce == 0 ? n0 : P.counts[bounce];
     const uint32_t* q = bounce == 0 ? nullptr : P.queue[bounce & 1];
     uint32_t* qnext = P.queue[(bounce + 1) & 1];
@@ -785,11 +793,14 @@ __global__ void __launch_bounds__(kShadeBlock) __attribute__((amdgpu_waves_per_e
             uint32_t gslot = 0;
             if (i < n) {
                 gslot = q ? q[i] : i;
-                if ((int)P.hit[gslot].y < 0) {
-                    const F3 dir = xyz(P.ray[2 * (size_t)gslot + 1]);
-                    const F3 C = xyz(P.C[gslot]) + xyz(P.T[gslot]) * sample_environment(S, dir);
-                    P.C[gslot] = f4(C, 0.0f);
-                } else hit = true;
+                const int hinst = (int)P.hit[gslot].y;
+                if (hinst < 0) {
+                    if (do_miss) {
+                        const F3 dir = xyz(P.ray[2 * (size_t)gslot + 1]);
+                        const F3 C = xyz(P.C[gslot]) + xyz(P.T[gslot]) * sample_environment(S, dir);
+                        P.C[gslot] = f4(C, 0.0f);
+                    }
+                } else hit = S.materials[S.insts[hinst].material].kind == KIND;
             }
             const unsigned long long hm = __ballot(hit);
             if (hit) hits[nh + (uint32_t)__popcll(hm & lt)] = gslot;
@@ -831,7 +842,7 @@ __global__ void __launch_bounds__(kShadeBlock) __attribute__((amdgpu_waves_per_e
                 F3 wo = -1.0f * r.d;
                 wo = wo / len(wo);
                 MatCtx m;
-                mat_prepare(S, h, m);
+                mat_prepare<KIND>(S, h, m);
                 // ---- SampleLights / EstimateDirect (render.h:26-105)
                 uint32_t flags = 0;
                 if (S.num_lights > 0) {
@@ -1133,6 +1144,7 @@ struct mi355pt_scene {
     DevBuf<float4> bvh_nodes, tris, attrs, recs; DevBuf<uint32_t> faces; DevBuf<float> normals, uvw, tangents, bitangents;
     DevBuf<mi355pt_material> materials; DevBuf<mi355pt_texmap> texmaps; DevBuf<DTexture> textures; DevBuf<DLight> lights; DevBuf<float> light_data;
     bool model_lights = false;        // some light sits on a Model: its own-object test is a BVH traversal (k_trace<2>)
+    uint32_t mtl_kinds = 0;           // bit 0: some material is Disney, bit 1: some is Cook-Torrance ("standard")
     // Renderers keep a pointer to their scene: scene_destroy while some are alive only marks the scene, and the last
     // render_destroy frees it (a reference maintainer's Restart() tears things down in whatever order it likes).
     std::mutex life; int renderers = 0; bool doomed = false;
@@ -1472,6 +1484,10 @@ int mi355pt_scene_create(const mi355pt_scene_desc* desc, int32_t device, mi355pt
     // ---- materials / textures
     std::vector<mi355pt_material> materials(desc->materials, desc->materials + desc->num_materials);
     std::vector<mi355pt_texmap> texmaps(desc->texmaps, desc->texmaps + desc->num_texmaps);
+    for (auto& m : materials) {
+        if (m.kind != MI355PT_MTL_DISNEY && m.kind != MI355PT_MTL_STANDARD) return fail(MI355PT_ERR_UNSUPPORTED, "unknown material kind");
+        sc->mtl_kinds |= m.kind == MI355PT_MTL_DISNEY ? 1u : 2u;
+    }
     auto bad_map = [&](int m) { return m >= (int)desc->num_texmaps; };
     for (auto& m : materials) if (bad_map(m.albedo_map) || bad_map(m.roughness_map) || bad_map(m.metalness_map) || bad_map(m.normal_map)) return fail(MI355PT_ERR_INVALID, "bad texmap index");
     for (auto& m : texmaps) if (m.texture >= (int)desc->num_textures) return fail(MI355PT_ERR_INVALID, "bad texture index");
@@ -1811,7 +1827,10 @@ int run_paths(mi355pt_render* r, uint32_t n, uint32_t jitter = 1, uint32_t only_
         }
         if (pending) { HIP_TRY(hipStreamWaitEvent(r->stream, r->join[b - 1], 0)); pending = false; last_join = b - 1; }
         ev_begin(r, 1, r->stream);
-        hipLaunchKernelGGL(k_shade, dim3(gs), dim3(kShadeBlock), 0, r->stream, S, r->cam, P, prm, b, n);
+        // one launch per material model present in the scene (k_shade<KIND>); the first one also finishes the misses
+        const uint32_t kinds = r->scene->mtl_kinds ? r->scene->mtl_kinds : 1u;
+        if (kinds & 1u) hipLaunchKernelGGL(k_shade<MI355PT_MTL_DISNEY>, dim3(gs), dim3(kShadeBlock), 0, r->stream, S, r->cam, P, prm, b, n, 1u);
+        if (kinds & 2u) hipLaunchKernelGGL(k_shade<MI355PT_MTL_STANDARD>, dim3(gs), dim3(kShadeBlock), 0, r->stream, S, r->cam, P, prm, b, n, (kinds & 1u) ? 0u : 1u);
         ev_end(r, r->stream);
         // the next bounce's closest-hit trace is enqueued BEFORE this bounce's visibility trace: it is the critical path,
         // and the kernel that is dispatched first fills the chip first

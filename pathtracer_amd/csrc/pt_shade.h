@@ -430,9 +430,12 @@ struct MatCtx {
     F3 brdfN, Ngeo, albedo, emission;
     float rough_raw, rough_eval, metal;
 };
+// KIND >= 0: the caller knows the material kind (k_shade<KIND> only takes hits of that kind): the other model's code, and
+// the registers its values would occupy, drop out at compile time.
+template <int KIND = -1>
 PT_DEV void mat_prepare(const DScene& S, const Surf& h, MatCtx& m) {
     const mi355pt_material& mt = S.materials[h.mtl];
-    m.kind = mt.kind;
+    m.kind = KIND >= 0 ? KIND : mt.kind;
     F3 N = h.N; N = N / len(N);
     m.Ngeo = N;
     m.brdfN = N;
@@ -443,7 +446,7 @@ PT_DEV void mat_prepare(const DScene& S, const Surf& h, MatCtx& m) {
         m.brdfN = b / len(b);
     }
     m.emission = f3(0, 0, 0);
-    if (mt.kind == MI355PT_MTL_DISNEY) {
+    if (m.kind == MI355PT_MTL_DISNEY) {
         m.d.base = textured_color_srgb(S, mt.albedo, mt.albedo_map, h);
         m.d.roughness = textured_color(S, mt.roughness, mt.roughness_map, h).x;
         m.d.metallic = textured_color(S, mt.metalness, mt.metalness_map, h).x;
