@@ -184,7 +184,7 @@ def main():
             "ms_per_sample": dt / args.steps / args.spp_per_step * 1e3,
             "rays_per_sample": rays_total / max(samples_total, 1.0),
         }
-    # ---- roofline of the dominant kernel (k_trace<closest>, the extend stage): algorithmic bytes / measured launch time
+    # ---- roofline of the workload's dominant kernel: algorithmic bytes / measured launch time (HIP events on its stream)
     if rank == 0 and not args.no_roofline:
         ext_ms, launches = st["extend_ms"], st["extend_launches"]
         closest = st["closest_rays"]
@@ -200,7 +200,7 @@ def main():
         # In the timed region k_trace<closest>(b + 1) shares the CUs with k_trace<any>(b), so its launches last longer
         # there although the step is shorter; `frac` is the timed region's, `frac_exclusive` this step's.
         pt.set_overlap(1 << 30)
-        pt.set_profiling(events=1, count_work=False)
+        pt.set_profiling(events=2, count_work=False)
         pt.reset_stats()
         pt.step(spp_step)
         pt.sync()
@@ -215,24 +215,49 @@ def main():
         n_tri = cs["bvh_tri_tests"] / max(cs["closest_rays"], 1)
         bytes_per_ray = NODE_BYTES * n_node + TRI_BYTES * n_tri + QUEUE_BYTES
         achieved = closest * bytes_per_ray / (ext_ms * 1e-3) / 1e9 if ext_ms > 0 else 0.0
-        # HBM traffic per launch from the PMC passes of this same command (tools/gpu_measure.sh; FETCH_SIZE and
-        # WRITE_SIZE in separate runs, corrected as MI355X_MICROARCH.md prescribes), committed under profiles/
-        traffic = None
+        # HBM traffic per launch: NOT measured by this run.  It comes from the builder's PMC passes of the same kernels
+        # (tools/gpu_measure.sh -> tools/pmc_traffic.py -> profiles/pmc_traffic.json; FETCH_SIZE and WRITE_SIZE in separate runs,
+        # FETCH_SIZE scaled by the factor calibrated for scattered 64-B records, tools/calib_records.hip), and is reported only
+        # while the kernel sources are the ones those passes ran.
+        traffic, traffic_source, tj = None, None, None
         tp = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tp) and args.workload == "c4" and world == 1:
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import pmc_traffic
             with open(tp) as f:
-                traffic = json.load(f).get("k_trace_closest_bytes_per_launch")
-        out["roofline"] = {"bound": "hbm", "kernel": "k_trace<closest> (extend)", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                           "bytes_per_ray": bytes_per_ray, "n_node_per_ray": n_node, "n_tri_per_ray": n_tri,
-                           "launches": int(launches), "avg_launch_ms": ext_ms / max(launches, 1),
-                           "frac_exclusive": (xs["closest_rays"] * bytes_per_ray / (xs["extend_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS) if xs["extend_ms"] > 0 else None,
-                           "avg_launch_ms_exclusive": xs["extend_ms"] / max(xs["extend_launches"], 1),
-                           # measured HBM rate of the kernel alone: PMC traffic per launch over the exclusive launch time
-                           "traffic_gbs_exclusive": (traffic / (xs["extend_ms"] / max(xs["extend_launches"], 1) * 1e-3) / 1e9) if traffic else None,
-                           "avg_bytes_per_launch": closest * bytes_per_ray / max(launches, 1),
-                           "shadow_n_node_per_ray": cs["shadow_node_visits"] / max(cs["shadow_rays"], 1),
-                           "shadow_n_tri_per_ray": cs["shadow_tri_tests"] / max(cs["shadow_rays"], 1)}
+                tj = json.load(f)
+            if tj.get("kernel_source_hash") == pmc_traffic.source_hash() and tj.get("spp_per_step") == args.spp_per_step:
+                traffic_source = f"profiles/pmc_traffic.json (builder PMC pass {tj.get('tag')}, not this run; FETCH_SIZE x {tj.get('fetch_size_factor_scattered_records'):.2f} per tools/calib_records.hip)"
+            else:
+                traffic_source = "none: profiles/pmc_traffic.json was taken from other kernel sources or another batch size"
+                tj = None
+        trace = {"bound": "hbm", "kernel": "k_trace<closest> (extend)", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                 "frac": achieved / HBM_PEAK_GBS, "traffic": tj.get("k_trace_closest_bytes_per_launch") if tj else None, "traffic_source": traffic_source,
+                 "bytes_per_ray": bytes_per_ray, "n_node_per_ray": n_node, "n_tri_per_ray": n_tri,
+                 "launches": int(launches), "avg_launch_ms": ext_ms / max(launches, 1),
+                 "frac_exclusive": (xs["closest_rays"] * bytes_per_ray / (xs["extend_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS) if xs["extend_ms"] > 0 else None,
+                 "avg_launch_ms_exclusive": xs["extend_ms"] / max(xs["extend_launches"], 1),
+                 # what the memory system sustains for this access shape: random 64-B records of a 1 GiB table, measured by
+                 # tools/calib_records.hip on the same GPU model (3.5 TB/s; the 8 TB/s peak is a streaming figure)
+                 "scattered_record_ceiling_gbs": 3540.0,
+                 "avg_bytes_per_launch": closest * bytes_per_ray / max(launches, 1),
+                 "top_records_in_lds_per_ray": cs["debug"][7] / max(cs["closest_rays"], 1),
+                 "shadow_n_node_per_ray": cs["shadow_node_visits"] / max(cs["shadow_rays"], 1),
+                 "shadow_n_tri_per_ray": cs["shadow_tri_tests"] / max(cs["shadow_rays"], 1)}
+        # k_shade: SURVEY 8(d) per vertex: 96 B attributes + 128 B path state + 4 texels x 3 B per bilinear lookup
+        verts, taps = xs["shaded_vertices"], xs["texture_taps"]
+        shade_bytes = verts * (96.0 + 128.0) + taps * 12.0
+        shade_ach = shade_bytes / (xs["shade_ms"] * 1e-3) / 1e9 if xs["shade_ms"] > 0 else 0.0
+        shade = {"bound": "hbm", "kernel": "k_shade", "achieved": shade_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": shade_ach / HBM_PEAK_GBS,
+                 "traffic": tj.get("k_shade_bytes_per_launch") if tj else None, "traffic_source": traffic_source,
+                 "bytes_per_vertex": shade_bytes / max(verts, 1), "vertices": int(verts), "texture_lookups_per_vertex": taps / max(verts, 1),
+                 "ms_exclusive": xs["shade_ms"],
+                 "note": "instruction-bound: about 4 000 VALU wave-instructions per vertex (DESIGN.md section 3); the HBM fraction is reported because the contract asks for it"}
+        # the workload's dominant kernel goes to `roofline`, the other is kept beside it
+        if xs["shade_ms"] > xs["extend_ms"]:
+            out["roofline"], out["roofline_extend"] = shade, trace
+        else:
+            out["roofline"], out["roofline_shade"] = trace, shade
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(scene, pt, args)
     if rank == 0:

@@ -206,6 +206,8 @@ typedef struct mi355pt_stats {
     double   other_ms;
     uint64_t extend_launches;
     uint64_t debug[8];          /* counting builds: kernel-internal utilisation counters */
+    uint64_t shaded_vertices;   /* k_shade: path vertices shaded (hits)                 */
+    uint64_t texture_taps;      /* k_shade: bilinear texture lookups (32 per map with ray differentials, else 1) */
 } mi355pt_stats;
 
 typedef struct mi355pt_scene  mi355pt_scene;    /* opaque: flattened scene in HBM      */

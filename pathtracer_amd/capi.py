@@ -87,7 +87,8 @@ class RenderParams(C.Structure):
 class Stats(C.Structure):
     _fields_ = [("closest_rays", u64), ("shadow_rays", u64), ("samples", u64), ("bvh_node_visits", u64),
                 ("bvh_tri_tests", u64), ("shadow_node_visits", u64), ("shadow_tri_tests", u64), ("max_nodes_per_ray", u64), ("extend_ms", C.c_double), ("shade_ms", C.c_double),
-                ("connect_ms", C.c_double), ("other_ms", C.c_double), ("extend_launches", u64), ("debug", u64 * 8)]
+                ("connect_ms", C.c_double), ("other_ms", C.c_double), ("extend_launches", u64), ("debug", u64 * 8),
+                ("shaded_vertices", u64), ("texture_taps", u64)]
 
 
 def make_params(width, height, seed=0x5EED, max_bounces=30, rr_start=3, sample_offset=0, sample_stride=1, device=0,

@@ -64,6 +64,7 @@ struct DPaths {
     uint32_t *spill;      // per resident wave: kStackSize x 64 dwords, the part of a lane's stack below its LDS window
     uint32_t *spill_any;  // the same for k_trace<ANY>, which may run beside k_trace<closest> of the next bounce
     unsigned long long *stat;   // [0] closest rays [1] shadow rays [2] samples [3,4] extend node visits / tri tests [5,6] visibility ditto [7] guard
+                                // [8..15] counting builds' diagnostics [16] vertices shaded [17] bilinear texture lookups
 };
 struct Params { uint32_t seed, width, height, max_bounces, rr_start, stack_entries, node_lanes, owner_lanes, gen, use_prep, no_cull, ntop; };
 
@@ -79,6 +80,7 @@ __device__ __forceinline__ HitRec load_hit(const DPaths& P, uint32_t slot) {
 }
 
 constexpr int kBlock = kTravBlock;
+constexpr int kNumStat = 24;          // DPaths::stat entries
 
 // wave64 compaction: one atomic per wave (ballot + mbcnt prefix)
 __device__ __forceinline__ void wave_enqueue(bool pred, uint32_t value, uint32_t* queue, uint32_t* counter) {
@@ -761,6 +763,7 @@ k_shade(DScene S, DCamera cam, DPaths P, Params prm, uint32_t bounce, uint32_t n
     __shared__ uint32_t ob_alive[kOut], ob_sq[kOut], ob_vq[2 * kOut];
     uint32_t na = 0, ns = 0, nv = 0;                              // wave-uniform fill counts
     unsigned long long mis_blocked = 0;                           // LightVisTest calls decided here (per lane)
+    unsigned long long n_vert = 0, n_taps = 0;                    // vertices shaded, bilinear texture lookups (bench.py's k_shade roofline)
     auto flush = [&]() {
         __syncthreads();
         if (na) {
@@ -843,6 +846,11 @@ k_shade(DScene S, DCamera cam, DPaths P, Params prm, uint32_t bounce, uint32_t n
                 wo = wo / len(wo);
                 MatCtx m;
                 mat_prepare<KIND>(S, h, m);
+                {
+                    const mi355pt_material& mt = S.materials[h.mtl];
+                    const uint32_t nm = (mt.albedo_map >= 0) + (mt.roughness_map >= 0) + (mt.metalness_map >= 0) + (mt.normal_map >= 0);
+                    n_vert++; n_taps += nm * (hasDiff ? 32u : 1u);
+                }
                 // ---- SampleLights / EstimateDirect (render.h:26-105)
                 uint32_t flags = 0;
                 if (S.num_lights > 0) {
@@ -932,6 +940,7 @@ k_shade(DScene S, DCamera cam, DPaths P, Params prm, uint32_t bounce, uint32_t n
         }
     }
     wave_add64(mis_blocked, &P.stat[1]);
+    wave_add64(n_vert, &P.stat[16]); wave_add64(n_taps, &P.stat[17]);
 }
 
 // ---------------------------------------------------------------------- connect (NEE shadow ray + MIS)
@@ -1644,8 +1653,8 @@ int mi355pt_render_create(mi355pt_scene* scene, const mi355pt_render_params* par
     if (const char* e = getenv("MI355PT_PREP_MIN_PATHS")) r->prep_min_paths = (uint32_t)std::max(0, atoi(e));
     if (r->prep_bounces) HIP_TRY(dalloc((void**)&P.prep, cap * 4 * sizeof(float4)));
     HIP_TRY(dalloc((void**)&P.vis, cap * 2));
-    HIP_TRY(dalloc((void**)&P.stat, 16 * sizeof(unsigned long long)));
-    HIP_TRY(hipMemsetAsync(P.stat, 0, 16 * sizeof(unsigned long long), r->stream));
+    HIP_TRY(dalloc((void**)&P.stat, kNumStat * sizeof(unsigned long long)));
+    HIP_TRY(hipMemsetAsync(P.stat, 0, kNumStat * sizeof(unsigned long long), r->stream));
     HIP_TRY(dalloc((void**)&r->mean, npix * 12)); HIP_TRY(dalloc((void**)&r->cnt, npix * 4)); HIP_TRY(dalloc((void**)&r->rgb8, npix * 3));
     // on the renderer's own (non-blocking) stream: a null-stream memset would not be ordered before its kernels
     HIP_TRY(hipMemsetAsync(r->mean, 0, npix * 12, r->stream)); HIP_TRY(hipMemsetAsync(r->cnt, 0, npix * 4, r->stream));
@@ -2083,20 +2092,21 @@ int mi355pt_render_stats(mi355pt_render* r, mi355pt_stats* st) {
     if (!r || !st) return fail(MI355PT_ERR_INVALID, "null argument");
     PT_LOCK(r);
     if (int rc = mi355pt_render_sync(r)) return rc;
-    unsigned long long h[16];
+    unsigned long long h[kNumStat];
     HIP_TRY(hipMemcpy(h, r->P.stat, sizeof(h), hipMemcpyDeviceToHost));
     for (int i = 0; i < 8; i++) st->debug[i] = h[8 + i];
     st->closest_rays = h[0]; st->shadow_rays = h[1]; st->samples = h[2]; st->bvh_node_visits = h[3]; st->bvh_tri_tests = h[4];
     st->shadow_node_visits = h[5]; st->shadow_tri_tests = h[6]; st->max_nodes_per_ray = 0;
     st->extend_ms = r->ms[0]; st->shade_ms = r->ms[1]; st->connect_ms = r->ms[2]; st->other_ms = r->ms[3];
     st->extend_launches = r->extend_launches;
+    st->shaded_vertices = h[16]; st->texture_taps = h[17];
     return MI355PT_OK;
 }
 int mi355pt_render_reset_stats(mi355pt_render* r) {
     if (!r) return fail(MI355PT_ERR_INVALID, "null argument");
     PT_LOCK(r);
     if (int rc = mi355pt_render_sync(r)) return rc;
-    HIP_TRY(hipMemsetAsync(r->P.stat, 0, 16 * sizeof(unsigned long long), r->stream));
+    HIP_TRY(hipMemsetAsync(r->P.stat, 0, kNumStat * sizeof(unsigned long long), r->stream));
     HIP_TRY(hipStreamSynchronize(r->stream));
     for (double& m : r->ms) m = 0;
     r->extend_launches = 0;
