@@ -9,6 +9,7 @@
  *     PathTracer::Join()  blocks until stopped    PathTracer::Join()
  *     std::atomic<bool> outputing (global)        PathTracer::outputing       polled once per sample (pathtracer.cpp:95-99)
  *     renderImage.GetPixels()  Color24[w*h]       PathTracer::GetPixels()     RGB8, row-major, y = 0 top, truncating
+ *     GUI poll every 0.3 s (window.cpp:170-174)   PathTracer::CopyPixels()    a whole frame + its sample count, beside a live Run()
  *
  * The reference's methods are void and have no error channel; here every failed call throws
  * std::runtime_error carrying mi355pt_last_error() -- there is no CPU fallback to fall back to.
@@ -19,6 +20,7 @@
 #pragma once
 #include <atomic>
 #include <cstdint>
+#include <mutex>
 #include <stdexcept>
 #include <string>
 #include <thread>
@@ -51,7 +53,7 @@ public:
         p.seed = seed_; p.sample_offset = 0; p.sample_stride = 1; p.device = device_;
         p.tile_size = 0; p.tile_offset = 0; p.tile_stride = 1;
         check(mi355pt_render_create(scene_, &p, &render_), "mi355pt_render_create");
-        pixels_.assign((size_t)w * h * 3, 0);
+        { std::lock_guard<std::mutex> g(frame_mu_); pixels_.assign((size_t)w * h * 3, 0); back_.assign((size_t)w * h * 3, 0); }
         samples_ = 0;
         outputing = false;
     }
@@ -64,10 +66,12 @@ public:
         worker_ = std::thread([this] {
             while (!outputing.load() && (limit_ == 0 || samples_ < limit_)) {
                 if (mi355pt_render_step(render_, 1) != MI355PT_OK || mi355pt_render_sync(render_) != MI355PT_OK ||
-                    mi355pt_render_read_rgb8(render_, pixels_.data()) != MI355PT_OK) {
+                    mi355pt_render_read_rgb8(render_, back_.data()) != MI355PT_OK) {
                     error_ = mi355pt_last_error();
                     return;
                 }
+                std::lock_guard<std::mutex> g(frame_mu_);       // publish the frame and its sample count together
+                pixels_.swap(back_);
                 samples_++;
             }
         });
@@ -82,7 +86,15 @@ public:
 
     void SetSampleLimit(uint64_t spp) { limit_ = spp; }
     uint64_t Samples() const { return samples_; }
-    const uint8_t* GetPixels() const { return pixels_.data(); }      // renderImage.GetPixels() (src/raytracer.cpp:449)
+    /* renderImage.GetPixels() (src/raytracer.cpp:449).  The pointer is stable while the tracer is stopped; a GUI thread
+     * that polls beside a live Run() (the reference's 0.3 s timer, src/window.cpp:170-174) takes CopyPixels instead, which
+     * returns a whole frame and the number of samples in it.  */
+    const uint8_t* GetPixels() const { return pixels_.data(); }
+    uint64_t CopyPixels(std::vector<uint8_t>& out) {
+        std::lock_guard<std::mutex> g(frame_mu_);
+        out = pixels_;
+        return samples_;
+    }
     mi355pt_render* Handle() const { return render_; }
 
     std::atomic<bool> outputing{false};
@@ -93,7 +105,7 @@ private:
     }
     int device_; uint32_t seed_;
     mi355pt_scene* scene_ = nullptr; mi355pt_render* render_ = nullptr;
-    std::vector<uint8_t> pixels_;
+    std::vector<uint8_t> pixels_, back_; std::mutex frame_mu_;
     std::thread worker_; std::string error_;
     std::atomic<uint64_t> samples_{0}; uint64_t limit_ = 0;
 };

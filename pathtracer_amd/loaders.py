@@ -16,10 +16,11 @@ Deliberate differences, each because the reference's own behaviour is a crash or
 not part of this repo:
   * `light="10.6"` (one token) means (10.6, 10.6, 10.6); the reference reads tokens[0..2] of a one-token
     vector (src/utils.cpp:284-286) and segfaults on its own assets/cornell.xml;
-  * OBJ import does not go through assimp: faces are fan-triangulated in file order and a vertex is emitted
-    per distinct (v, vt, vn) triple.  Triangle counts match the survey's probe of the reference importer for
-    the shipped meshes (teapot 6 320, teapot_lowpoly 240, cat 2 082); vertex order may differ -- "parity
-    unpinned" for anything that depends on it (nothing in the renderer does: hits are reported by face);
+  * OBJ import does not call assimp (not available here): obj_import.py restates what assimp 5.0.0 does to an OBJ
+    file under ModelLoader's flags -- its own number parser, quad fans, flat normals, tangent-aware vertex joining,
+    the root-node-plus-one-child-per-group tree -- and lists what the sources leave undetermined (n-gons with more
+    than four corners, tie order in the spatial sort).  Triangle counts match the survey's probe of the reference
+    importer (teapot 6 320, teapot_lowpoly 240, cat 2 082); vertex counts were not probed: "parity unpinned" there;
   * `type="obj"` objects and `type="blinn"` materials raise: the reference has no loader branch for them either
     (src/xmlload.cpp:228-256, 314-431).
 """
@@ -29,7 +30,7 @@ import xml.etree.ElementTree as ET
 import numpy as np
 
 from .scene import (Camera, F, LightComponent, Mesh, Model, MtlDisney, MtlStandard, Node, Plane, Scene, Sphere, TextureChecker,
-                    TextureFile, TextureMap, load_obj)
+                    TextureFile, TextureMap)
 
 
 class SceneFormatError(ValueError):
@@ -113,11 +114,22 @@ def BuildTextModel(path):
 
 
 def LoadModel(path, light=None):
-    """ModelLoader::Load: a node (identity transform) carrying the imported Model and the parent's light."""
-    n = Node(os.path.basename(path), Model([load_obj(path)]))
+    """ModelLoader::Load / ProcessNode (include/model.h:359-424) over the importer's node tree: assimp's OBJ importer
+    makes a root aiNode without meshes and one child per object / group holding that object's meshes
+    (code/Obj/ObjFileImporter.cpp:163-212, :256-310), all with identity transforms; every imported node gets the parent's
+    light (model.h:389), a node with meshes gets a Model of them.  The extra identity level matters: a ray goes through
+    Node::ToNodeCoords once more (`TransformTo(p + dir) - TransformTo(p)`, include/node.h:174-180)."""
+    from .obj_import import import_obj
+    imp = import_obj(path)
+    root = Node(imp.name)
     if light is not None:
-        n.SetLight(light)
-    return n
+        root.SetLight(light)
+    for name, meshes in imp.objects:
+        ch = Node(name, Model([Mesh(m.vertices, m.normals, m.uvw, m.faces[:, :3]) for m in meshes]) if meshes else None)
+        if light is not None:
+            ch.SetLight(light)
+        root.AppendChild(ch)
+    return root
 
 
 # ------------------------------------------------------------------ textures / materials

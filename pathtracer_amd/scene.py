@@ -569,49 +569,13 @@ def load_hdr(path):
 
 
 def load_obj(path):
-    """Wavefront OBJ -> Mesh.  Fan triangulation in file order; a vertex per distinct
-    (v, vt, vn) triple in order of first use; flat face normals when the file has none.
-    (The reference imports through assimp -- SURVEY 8(f)-1 "next"; face order may differ.)"""
-    vs, vts, vns, tris = [], [], [], []
-    key2idx, verts, norms, uvs = {}, [], [], []
-    has_n = False
-    with open(path) as f:
-        for line in f:
-            if line.startswith("v "):
-                vs.append([float(x) for x in line.split()[1:4]])
-            elif line.startswith("vt "):
-                t = [float(x) for x in line.split()[1:4]]
-                vts.append((t + [0.0, 0.0])[:3])
-            elif line.startswith("vn "):
-                vns.append([float(x) for x in line.split()[1:4]])
-                has_n = True
-            elif line.startswith("f "):
-                corner = []
-                for tok in line.split()[1:]:
-                    p = (tok.split("/") + ["", ""])[:3]
-                    vi = int(p[0]); ti = int(p[1]) if p[1] else 0; ni = int(p[2]) if p[2] else 0
-                    vi = vi - 1 if vi > 0 else len(vs) + vi
-                    ti = ti - 1 if ti > 0 else (len(vts) + ti if ti < 0 else -1)
-                    ni = ni - 1 if ni > 0 else (len(vns) + ni if ni < 0 else -1)
-                    corner.append((vi, ti, ni))
-                for k in range(1, len(corner) - 1):
-                    tri = []
-                    for c in (corner[0], corner[k], corner[k + 1]):
-                        key = c if has_n else (c[0], c[1], len(tris))      # flat normals: no sharing
-                        if key not in key2idx:
-                            key2idx[key] = len(verts)
-                            verts.append(vs[c[0]])
-                            uvs.append(vts[c[1]] if c[1] >= 0 else [0.0, 0.0, 0.0])
-                            norms.append(vns[c[2]] if (has_n and c[2] >= 0) else [0.0, 0.0, 0.0])
-                        tri.append(key2idx[key])
-                    tris.append(tri)
-    verts = np.asarray(verts, dtype=F); uvs = np.asarray(uvs, dtype=F); norms = np.asarray(norms, dtype=F)
-    tris = np.asarray(tris, dtype=np.uint32)
-    if not has_n:
-        e1 = verts[tris[:, 1]] - verts[tris[:, 0]]
-        e2 = verts[tris[:, 2]] - verts[tris[:, 0]]
-        n = np.cross(e1, e2).astype(F)
-        n = (n / np.maximum(np.linalg.norm(n, axis=1, keepdims=True), 1e-30)).astype(F)
-        for k in range(3):
-            norms[tris[:, k]] = n
-    return Mesh(verts, norms, uvs, tris)
+    """Wavefront OBJ -> the one Mesh the file holds, as the reference's importer (assimp 5.0.0 with ModelLoader's flags,
+    include/model.h:359-371, then Mesh::ProcessAssimpData, include/mesh.h:87-147) produces it: see obj_import.py for the
+    steps (assimp's own number parser, quad fans, flat normals, tangent-aware vertex joining).  Files with several
+    objects / materials give several meshes: use obj_import.import_obj or loaders.LoadModel for those."""
+    from .obj_import import import_obj
+    meshes = [m for _, ms in import_obj(path).objects for m in ms]
+    if len(meshes) != 1:
+        raise ValueError(f"{path}: {len(meshes)} meshes; load_obj handles single-mesh files, use loaders.LoadModel")
+    m = meshes[0]
+    return Mesh(m.vertices, m.normals, m.uvw, m.faces[:, :3])        # a fresh copy: the importer's result is cached

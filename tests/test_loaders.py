@@ -68,10 +68,15 @@ def test_nested_scene_semantics(monkeypatch):
     assert tm.obj.meshes[0].faces.shape == (2, 4) and tm.obj.meshes[0].vertices.shape == (4, 3)
     assert np.array_equal(tm.obj.meshes[0].aabb, np.array([-1, 0, -1, 1, 2, -1], dtype=np.float32))
     assert tuple(tm.tm[[0, 4, 8]]) == (2.0, 3.0, 4.0)
-    # model: the imported node hangs under the object's node, which carries transform and material
-    mnode = [n for n in nodes if n.name.endswith("teapot_lowpoly.obj") and n.obj is None][0]
-    assert len(mnode.children) == 1 and mnode.children[0].obj.meshes[0].faces.shape[0] == 240
-    assert mnode.children[0].GetMaterial() is gold
+    # model: the importer's tree (root aiNode without meshes -> one child per OBJ group with the meshes,
+    # ObjFileImporter.cpp:163-212) hangs under the object's node, which carries transform and material
+    mnode = [n for n in nodes if n.children and n.children[0].name == "teapot_lowpoly.obj"][0]
+    iroot = mnode.children[0]
+    assert mnode.obj is None and iroot.obj is None and len(iroot.children) == 1
+    grp = iroot.children[0]
+    assert grp.name == "Teapot001" and grp.obj.meshes[0].faces.shape[0] == 240
+    assert grp.GetMaterial() is gold
+    assert all(np.array_equal(n.tm, np.eye(3, dtype=np.float32).reshape(-1)) and not n.pos.any() for n in (iroot, grp))
     # camera
     c = s.camera
     assert (c.width, c.height, c.fov, c.dof) == (96, 64, 30.0, 0.5) and c.focaldist == pytest.approx(60.2)
