@@ -518,3 +518,57 @@ def test_edge_cases(kind, w, h, bounces):
     want = omp.reshape(w * h, 3, 3).astype(np.float64).mean(axis=1)
     assert common.rel_mse(mean, want) <= 1e-3
     pt.close_render()
+
+
+def _write_png(path, rgb):
+    """8-bit RGB PNG, zlib-compressed, filter 0 -- what the reference's lodepng decoder is given for its 1024^2 maps."""
+    import struct
+    import zlib
+    h, w, _ = rgb.shape
+    raw = b"".join(b"\x00" + rgb[y].tobytes() for y in range(h))
+
+    def chunk(t, body):
+        return struct.pack(">I", len(body)) + t + body + struct.pack(">I", zlib.crc32(t + body) & 0xFFFFFFFF)
+    with open(path, "wb") as f:
+        f.write(b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, 2, 0, 0, 0))
+                + chunk(b"IDAT", zlib.compress(raw, 6)) + chunk(b"IEND", b""))
+
+
+def test_c2_with_1024_png_maps(tmp_path):
+    """C2 as SURVEY 8(d) words it: four 1024^2 8-bit maps that arrive as PNG files (TextureFile::Load, src/texture.cpp:31-98,
+    vertical flip at :60), not the 256^2 in-memory arrays of the small parity scene.  Primary hits, the 32-tap filtered
+    bounce-0 lookups and the unfiltered later ones, against the oracle."""
+    from oracle.binding import OracleScene
+    from pathtracer_amd import scenes
+    from pathtracer_amd.scene import TextureFile
+    w, h = 160, 90
+    s = scenes.textured_c2(w, h, tex_size=1024)
+    seen = {}
+    for m in s.materials:
+        for mp in (m.albedo_map, m.normal_map, m.roughness_map, m.metalness_map):
+            if mp is None:
+                continue
+            t = mp.texture
+            if id(t) not in seen:
+                p = tmp_path / f"map{len(seen)}.png"
+                _write_png(str(p), t.data[::-1])                  # file rows top-down; the loader flips them back
+                seen[id(t)] = TextureFile(path=str(p))
+                assert seen[id(t)].data.shape == (1024, 1024, 3) and np.array_equal(seen[id(t)].data, t.data)
+            mp.texture = seen[id(t)]
+    assert len(seen) == 4
+    pt = PathTracer(s)
+    pt.Init(w, h)
+    orc = OracleScene(s)
+    node, mesh, face, t = pt.trace_primary()
+    onode, omesh, oface, ot, _ = orc.trace_primary(pt.params, 0, 0, w, h)
+    assert np.array_equal(node, onode) and np.array_equal(face, oface) and np.array_equal(t.view(np.uint32), ot.view(np.uint32))
+    rng = np.random.default_rng(21)
+    pixel = rng.integers(0, w * h, 3000).astype(np.uint32)
+    sample = rng.integers(0, 64, 3000).astype(np.uint32)
+    lin, _ = pt.sample_radiance(pixel, sample)
+    olin, _ = orc.sample_radiance(pt.params, pixel, sample)
+    frac, _ = common.radiance_agreement(lin, olin)
+    assert olin.max() > 0 and frac >= 0.999, f"only {frac:.5f} of samples within 1e-3"
+    pt.step(1); pt.sync()
+    assert pt.stats()["texture_taps"] > 32 * 4 * 1000            # filtered lookups really ran
+    pt.close_render()
