@@ -156,7 +156,21 @@ __device__ __forceinline__ void prepare_ray(const DScene& S, const DPaths& P, ui
 }
 
 // ---------------------------------------------------------------------- init
-__global__ void __launch_bounds__(kBlock) k_init(DPaths P, Params prm, uint32_t n, uint32_t pix_base, uint32_t npix_chunk,
+// Slot layout of a batch of `ns` samples of `npix` pixels (k_init and k_resolve): groups of `grp` pixels -- grp = 0 means one
+// group of all the pixels, i.e. sample-major -- and inside a group sample by sample.  The samples of a pixel block are then
+// neighbours in the queues, so the rays in flight at any time come from an `ns` times smaller part of the image.
+__device__ __forceinline__ uint32_t slot_of(uint32_t ipix, uint32_t s, uint32_t npix, uint32_t ns, uint32_t grp) {
+    if (!grp) return s * npix + ipix;
+    const uint32_t g = ipix / grp, first = g * grp, gsize = npix - first < grp ? npix - first : grp;
+    return first * ns + s * gsize + (ipix - first);
+}
+__device__ __forceinline__ void slot_to(uint32_t slot, uint32_t npix, uint32_t ns, uint32_t grp, uint32_t& ipix, uint32_t& s) {
+    if (!grp) { s = slot / npix; ipix = slot - s * npix; return; }
+    const uint32_t g = slot / (grp * ns), first = g * grp, gsize = npix - first < grp ? npix - first : grp;
+    const uint32_t rem = slot - first * ns;
+    s = rem / gsize; ipix = first + (rem - s * gsize);
+}
+__global__ void __launch_bounds__(kBlock) k_init(DPaths P, Params prm, uint32_t n, uint32_t pix_base, uint32_t npix_chunk, uint32_t grp,
                                                  const uint32_t* cnt, uint32_t sample_offset, uint32_t sample_stride,
                                                  const uint32_t* list_pix, const uint32_t* list_smp, const uint32_t* own,
                                                  DCamera cam, uint32_t with_rays, DScene S) {
@@ -164,8 +178,9 @@ __global__ void __launch_bounds__(kBlock) k_init(DPaths P, Params prm, uint32_t 
         uint32_t pixel, sample;
         if (list_pix) { pixel = list_pix[i]; sample = list_smp[i]; }
         else {
-            const uint32_t s = i / npix_chunk;
-            pixel = pix_base + (i - s * npix_chunk);
+            uint32_t s, ipix;
+            slot_to(i, npix_chunk, n / npix_chunk, grp, ipix, s);
+            pixel = pix_base + ipix;
             if (own) pixel = own[pixel];                 // tile split: the chunk indexes this renderer's pixel list
             sample = sample_offset + (cnt[pixel] + s) * sample_stride;
         }
@@ -1006,13 +1021,13 @@ __device__ __forceinline__ F3 finish_sample(F3 c, F3* linear) {
     return f3(a_powf(m.x, 0.4545f), a_powf(m.y, 0.4545f), a_powf(m.z, 0.4545f));
 }
 __global__ void __launch_bounds__(kBlock) k_resolve(DPaths P, float* mean, uint32_t* cnt, uint8_t* rgb8, uint32_t pix_base,
-                                                    uint32_t npix_chunk, uint32_t ns, const uint32_t* own) {
+                                                    uint32_t npix_chunk, uint32_t ns, const uint32_t* own, uint32_t grp) {
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < npix_chunk; i += gridDim.x * blockDim.x) {
         const uint32_t pixel = own ? own[pix_base + i] : pix_base + i;
         F3 c = f3(mean[3 * (size_t)pixel], mean[3 * (size_t)pixel + 1], mean[3 * (size_t)pixel + 2]);
         uint32_t n = cnt[pixel];
         for (uint32_t s = 0; s < ns; s++) {
-            const uint32_t slot = s * npix_chunk + i;
+            const uint32_t slot = slot_of(i, s, npix_chunk, ns, grp);
             const F3 smp = finish_sample(xyz(P.C[slot]), nullptr);
             n += 1;
             const float factor = 1.0f / (float)n;
@@ -1183,6 +1198,7 @@ struct mi355pt_render {
     hipStream_t side = nullptr;
     std::vector<hipEvent_t> fork, join;
     uint32_t overlap_from = 0;
+    uint32_t slot_group = 64;                       // pixels per slot group of a batch (slot_of; MI355PT_SLOT_GROUP, 0 = sample-major)
     unsigned long long* progress = nullptr;         // pinned host memory behind P.progress
     uint32_t gen = 0; bool progress_timeout = false;
     uint32_t prep_bounces = 0;                      // bounces whose closest-hit trace is fed by k_prepare (the large ones)
@@ -1625,11 +1641,13 @@ int mi355pt_render_create(mi355pt_scene* scene, const mi355pt_render_params* par
     // from bounce 0 by default: each launch's thin tail is filled by the other stream's kernel (C4: 24.2 -> 22.0 ms per sample)
     r->overlap_from = 0;
     if (const char* e = getenv("MI355PT_OVERLAP_FROM")) r->overlap_from = (uint32_t)std::max(0, atoi(e));
+    if (const char* e = getenv("MI355PT_SLOT_GROUP")) r->slot_group = (uint32_t)std::max(0, atoi(e));
     const size_t npix = (size_t)params->width * params->height;
-    // Path slots of one chunk.  Eight samples of a 4K frame fit (294 B per slot, 19.7 GB): a step of several samples runs them as ONE batch, and the fixed
+    // Path slots of one chunk.  Sixteen samples of a 4K frame fit (294 B per slot, 39.5 GB of the 288): a step of several samples runs them as ONE batch, and the fixed
     // cost of a batch -- above all the ~20 late bounces that a few thousand Russian-roulette survivors drag out at one ray's
     // latency each (3.4 of 18 ms for a single 4K sample of C4, profiles/r02b_timeline.txt) -- is paid once per batch.
-    size_t cap = 67108864;
+    // C4, samples per batch 8 / 16 / 24 / 32: 3 320 / 3 413 / 3 445 / 3 468 Mrays/s -- 16 is where the curve flattens.
+    size_t cap = 134217728;
     if (const char* e = getenv("MI355PT_MAX_PATHS")) cap = std::max<size_t>(65536, strtoull(e, nullptr, 10));
     cap = std::min(cap, std::max<size_t>(npix, 65536) * 64);
     cap = (cap + 63) & ~(size_t)63;
@@ -1678,10 +1696,24 @@ int mi355pt_render_create(mi355pt_scene* scene, const mi355pt_render_params* par
                     if (!split || ((y / ts) * tx + x / ts) % params->tile_stride == params->tile_offset) own.push_back(y * params->width + x);
         };
         if (bs == 1) block(0, 0, params->width, params->height);
-        else
-            for (uint32_t y0 = 0; y0 < params->height; y0 += bs)
-                for (uint32_t x0 = 0; x0 < params->width; x0 += bs)
-                    block(x0, y0, std::min(x0 + bs, params->width), std::min(y0 + bs, params->height));
+        else {
+            // ... and the blocks along a Z-order curve, so that the rays in flight at one time (a few hundred blocks) cover a
+            // compact patch of the image, not a strip one block high (MI355PT_BLOCK_ORDER=row: row-major blocks)
+            const uint32_t nbx = (params->width + bs - 1) / bs, nby = (params->height + bs - 1) / bs;
+            std::vector<std::pair<uint32_t, uint32_t>> order;      // (curve position, by * nbx + bx)
+            order.reserve((size_t)nbx * nby);
+            const char* bo = getenv("MI355PT_BLOCK_ORDER");
+            const bool zcurve = !(bo && !strcmp(bo, "row"));
+            auto spread = [](uint32_t v) { v &= 0xFFFFu; v = (v | (v << 8)) & 0x00FF00FFu; v = (v | (v << 4)) & 0x0F0F0F0Fu; v = (v | (v << 2)) & 0x33333333u; return (v | (v << 1)) & 0x55555555u; };
+            for (uint32_t by = 0; by < nby; by++)
+                for (uint32_t bx = 0; bx < nbx; bx++)
+                    order.push_back({zcurve ? (spread(bx) | (spread(by) << 1)) : by * nbx + bx, by * nbx + bx});
+            std::sort(order.begin(), order.end());
+            for (const auto& o : order) {
+                const uint32_t x0 = (o.second % nbx) * bs, y0 = (o.second / nbx) * bs;
+                block(x0, y0, std::min(x0 + bs, params->width), std::min(y0 + bs, params->height));
+            }
+        }
         if (split || bs != 1) {
             r->n_own = own.size();
             HIP_TRY(dalloc((void**)&r->own, std::max<size_t>(own.size(), 1) * 4));
@@ -1888,11 +1920,11 @@ int mi355pt_render_step(mi355pt_render* r, uint32_t spp) {
             const uint32_t n = np * ns;
             ev_begin(r, 3, r->stream);
             hipLaunchKernelGGL(k_init, dim3(grid_for(r, n)), dim3(kBlock), 0, r->stream, r->P, kprm,
-                               n, (uint32_t)pix_base, np, r->cnt, p.sample_offset, p.sample_stride, (const uint32_t*)nullptr, (const uint32_t*)nullptr, (const uint32_t*)r->own, r->cam, use_prepass(r, n) ? 2u : 1u, r->scene->d);
+                               n, (uint32_t)pix_base, np, r->slot_group, r->cnt, p.sample_offset, p.sample_stride, (const uint32_t*)nullptr, (const uint32_t*)nullptr, (const uint32_t*)r->own, r->cam, use_prepass(r, n) ? 2u : 1u, r->scene->d);
             ev_end(r, r->stream);
             if (int rc = run_paths(r, n, 2u, 0u, use_prepass(r, n))) return rc;
             ev_begin(r, 3, r->stream);
-            hipLaunchKernelGGL(k_resolve, dim3(grid_for(r, np)), dim3(kBlock), 0, r->stream, r->P, r->mean, r->cnt, r->rgb8, (uint32_t)pix_base, np, ns, (const uint32_t*)r->own);
+            hipLaunchKernelGGL(k_resolve, dim3(grid_for(r, np)), dim3(kBlock), 0, r->stream, r->P, r->mean, r->cnt, r->rgb8, (uint32_t)pix_base, np, ns, (const uint32_t*)r->own, r->slot_group);
             ev_end(r, r->stream);
         }
     }
@@ -2050,7 +2082,7 @@ int mi355pt_sample_radiance(mi355pt_render* r, const uint32_t* pixel, const uint
     const mi355pt_render_params& p = r->prm;
     const Params kprm{p.seed, p.width, p.height, p.max_bounces, p.rr_start, r->stack_entries, r->node_lanes, r->owner_lanes};
     hipLaunchKernelGGL(k_init, dim3(grid_for(r, count)), dim3(kBlock), 0, r->stream, r->P, kprm,
-                       count, 0u, 1u, (const uint32_t*)r->cnt, 0u, 1u, (const uint32_t*)dp, (const uint32_t*)ds, (const uint32_t*)nullptr, r->cam, use_prepass(r, count) ? 2u : 1u, r->scene->d);
+                       count, 0u, 1u, 0u, (const uint32_t*)r->cnt, 0u, 1u, (const uint32_t*)dp, (const uint32_t*)ds, (const uint32_t*)nullptr, r->cam, use_prepass(r, count) ? 2u : 1u, r->scene->d);
     const int rc = run_paths(r, count, 2u, 0u, use_prepass(r, count));
     if (rc == MI355PT_OK) hipLaunchKernelGGL(k_gather, dim3(grid_for(r, count)), dim3(kBlock), 0, r->stream, r->P, count, dl, dm);
     hipError_t e = hipStreamSynchronize(r->stream);
