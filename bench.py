@@ -121,6 +121,16 @@ def main():
         raise SystemExit("bench.py needs a gfx950 device; there is no CPU fallback")
 
     t0 = time.perf_counter()
+    # building a 100 M-triangle scene (C5), its counting-build step and its CPU leg take minutes in silence: a line on stderr
+    # every 30 s tells a watchdog (gpurun's 180 s rule) that the run is alive.  A host thread that sleeps does not touch the GPU.
+    import threading
+    building = threading.Event()
+    phase = ["building the scene"]
+
+    def heartbeat():
+        while not building.wait(30.0):
+            log(f"[bench] {phase[0]}, {time.perf_counter() - t0:.0f} s")
+    threading.Thread(target=heartbeat, daemon=True).start()
     scene, workload = build_scene(args)
     if args.split == "tile":
         ts, toff, tstride = distributed.rank_tile_split(rank, world, 64)
@@ -131,6 +141,7 @@ def main():
         pt = PathTracer(scene, device=device, seed=args.seed, sample_offset=off, sample_stride=stride)
         spp_step = args.spp_per_step
     pt.Init(args.width, args.height)
+    phase[0] = "running"
     if rank == 0:
         log(f"scene + BVH + upload: {time.perf_counter() - t0:.1f} s")
 

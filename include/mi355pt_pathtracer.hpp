@@ -65,14 +65,18 @@ public:
         error_.clear();
         worker_ = std::thread([this] {
             while (!outputing.load() && (limit_ == 0 || samples_ < limit_)) {
-                if (mi355pt_render_step(render_, 1) != MI355PT_OK || mi355pt_render_sync(render_) != MI355PT_OK ||
+                // samples of one step are traced as one batch (the renderer's path pool holds 16 of a 4K frame): faster per
+                // sample than single steps, at the price of a stop flag that is polled once per batch
+                const uint64_t left = limit_ ? limit_ - samples_ : per_step_;
+                const uint32_t k = (uint32_t)(left < per_step_ ? left : per_step_);
+                if (mi355pt_render_step(render_, k) != MI355PT_OK || mi355pt_render_sync(render_) != MI355PT_OK ||
                     mi355pt_render_read_rgb8(render_, back_.data()) != MI355PT_OK) {
                     error_ = mi355pt_last_error();
                     return;
                 }
                 std::lock_guard<std::mutex> g(frame_mu_);       // publish the frame and its sample count together
                 pixels_.swap(back_);
-                samples_++;
+                samples_ += k;
             }
         });
     }
@@ -85,6 +89,7 @@ public:
     void Stop() { outputing = true; if (worker_.joinable()) worker_.join(); }
 
     void SetSampleLimit(uint64_t spp) { limit_ = spp; }
+    void SetSamplesPerStep(uint32_t n) { per_step_ = n ? n : 1; }     // default 1: the stop flag is honoured after every sample
     uint64_t Samples() const { return samples_; }
     /* renderImage.GetPixels() (src/raytracer.cpp:449).  The pointer is stable while the tracer is stopped; a GUI thread
      * that polls beside a live Run() (the reference's 0.3 s timer, src/window.cpp:170-174) takes CopyPixels instead, which
@@ -107,7 +112,7 @@ private:
     mi355pt_scene* scene_ = nullptr; mi355pt_render* render_ = nullptr;
     std::vector<uint8_t> pixels_, back_; std::mutex frame_mu_;
     std::thread worker_; std::string error_;
-    std::atomic<uint64_t> samples_{0}; uint64_t limit_ = 0;
+    std::atomic<uint64_t> samples_{0}; uint64_t limit_ = 0; uint64_t per_step_ = 1;
 };
 
 }  // namespace mi355pt

@@ -28,9 +28,11 @@ int main(int argc, char** argv) {
         std::vector<uint8_t> first(pt.GetPixels(), pt.GetPixels() + (size_t)w * h * 3);
         pt.Init(w, h);
         pt.SetSampleLimit(spp);
+        pt.SetSamplesPerStep(4);                    // ... also when the samples are traced in batches of four
         pt.Run();
         pt.Join();
-        if (memcmp(first.data(), pt.GetPixels(), first.size()) != 0) { fprintf(stderr, "restart changed the image\n"); return 4; }
+        pt.SetSamplesPerStep(1);
+        if (pt.Samples() != spp || memcmp(first.data(), pt.GetPixels(), first.size()) != 0) { fprintf(stderr, "restart changed the image\n"); return 4; }
         // stop flag: an unbounded run ends when `outputing` is raised
         pt.Init(w, h);
         pt.SetSampleLimit(0);

@@ -12,7 +12,8 @@ for c in "c1 512 512 64 512 512 16" "c2 1920 1080 32 960 540 1" "c3 3840 2160 16
 import json, sys
 d = json.load(open(f"gpurun_out/{sys.argv[2]}/bench_{sys.argv[1]}.json"))
 print(sys.argv[1], round(d["value"], 1), "Mrays/s", round(d["ms_per_sample"], 3), "ms/sample", round(d["samples_per_pixel_per_s"], 1), "spp/s",
-      {k: round(v, 2) for k, v in d["kernel_ms"].items() if k != "steps"}, "frac", round(d["roofline"]["frac"], 3), "nodes/ray", round(d["roofline"]["n_node_per_ray"], 1),
+      {k: round(v, 2) for k, v in d["kernel_ms"].items() if k != "steps"}, "dominant", d["roofline"]["kernel"], "frac", round(d["roofline"]["frac"], 3), "nodes/ray", round(d.get("roofline_extend", d["roofline"])["n_node_per_ray"], 1),
       "| cpu", round(d["cpu_baseline"]["value"], 2), "Mrays/s on", d["cpu_baseline"]["cores"], "threads")
 PY
+  [ $? -eq 0 ] || exit 2
 done
