@@ -802,6 +802,12 @@ k_shade(DScene S, DCamera cam, DPaths P, Params prm, uint32_t bounce, uint32_t n
     const unsigned long long lt = (1ull << lane) - 1ull;
     uint32_t nh = 0;                                              // hits waiting in LDS (wave-uniform)
     uint32_t i0 = blockIdx.x * 64u;
+#ifdef PT_SHADE_PROBE     // where a wave's time goes (tools/shade_probe.py): gather / loads + surface + material / the rest
+    long long pk_t = clock64(), pk_gather = 0, pk_surf = 0, pk_rest = 0;
+#define PT_SHADE_TICK(acc) { const long long t_ = clock64(); acc += t_ - pk_t; pk_t = t_; }
+#else
+#define PT_SHADE_TICK(acc)
+#endif
     for (;;) {
         // ---- gather: misses are finished here (render.h:124-128), hits are collected
         while (nh < 64u && i0 < n) {
@@ -826,6 +832,7 @@ k_shade(DScene S, DCamera cam, DPaths P, Params prm, uint32_t bounce, uint32_t n
         }
         if (nh == 0) { flush(); break; }
         __syncthreads();
+        PT_SHADE_TICK(pk_gather)
         const uint32_t take = nh < 64u ? nh : 64u;
         const bool act = lane < take;
         const uint32_t slot = act ? hits[nh - take + lane] : 0u;
@@ -861,6 +868,10 @@ k_shade(DScene S, DCamera cam, DPaths P, Params prm, uint32_t bounce, uint32_t n
                 wo = wo / len(wo);
                 MatCtx m;
                 mat_prepare<KIND>(S, h, m);
+#ifdef PT_SHADE_PROBE
+                asm volatile("" :: "v"(m.brdfN.x), "v"(h.p.x) : "memory");
+                PT_SHADE_TICK(pk_surf)
+#endif
                 {
                     const mi355pt_material& mt = S.materials[h.mtl];
                     const uint32_t nm = (mt.albedo_map >= 0) + (mt.roughness_map >= 0) + (mt.metalness_map >= 0) + (mt.normal_map >= 0);
@@ -953,9 +964,13 @@ k_shade(DScene S, DCamera cam, DPaths P, Params prm, uint32_t bounce, uint32_t n
             na += (uint32_t)__popcll(ma); ns += (uint32_t)__popcll(ms); nv += (uint32_t)__popcll(m1) + (uint32_t)__popcll(m2);
             if (na > kOut - 64u || ns > kOut - 64u || nv > 2u * kOut - 128u) flush();
         }
+        PT_SHADE_TICK(pk_rest)
     }
     wave_add64(mis_blocked, &P.stat[1]);
     wave_add64(n_vert, &P.stat[16]); wave_add64(n_taps, &P.stat[17]);
+#ifdef PT_SHADE_PROBE
+    if (threadIdx.x == 0) { atomicAdd(&P.stat[8], (unsigned long long)pk_gather); atomicAdd(&P.stat[9], (unsigned long long)pk_surf); atomicAdd(&P.stat[10], (unsigned long long)pk_rest); }
+#endif
 }
 
 // ---------------------------------------------------------------------- connect (NEE shadow ray + MIS)
