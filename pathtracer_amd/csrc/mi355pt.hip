@@ -580,7 +580,11 @@ __global__ void __launch_bounds__(kExtBlockMax) k_trace(DScene S, DPaths P, Para
                         while (sp + 1u > lo + prm.stack_entries) { PT_SPILL(lo) = PT_STK(lo); lo++; }
                     }
                 }
+#ifdef PT_NO_FAST_SLAB    // A/B probe: the literal slab for every ray
+                const bool wave_fast = false;
+#else
                 const bool wave_fast = __ballot(want && !fastok) == 0ull;
+#endif
                 int fL = 0, fR = 0;                                       // leaf items of this step (negative) or 0
 #ifdef PT_PROBE_SALU      // cost-model probes (tools/ab_bench.sh): 32 extra scalar / vector instructions per node step
                 { uint32_t t_ = it; asm volatile(".rept 32\n\ts_add_u32 %0, %0, 1\n\t.endr" : "+s"(t_)); if (t_ == 0xFFFFFFFFu) break; }
