@@ -18,6 +18,7 @@
 #include <string>
 #include <chrono>
 #include <thread>
+#include <array>
 #include <vector>
 
 #include "../../include/mi355pt.h"
@@ -768,7 +769,7 @@ constexpr int kShadeBlock = 64;
 // KIND: the material model this instance shades (MI355PT_MTL_DISNEY / _STANDARD: two code bodies, disneyMaterial.h:85-203 and
 // standardMaterial.h:33-103): hits on the other kind are left to the other instance's launch, and only the instance with
 // `do_miss` finishes the misses.  A scene with one kind of material runs one instance.
-template <int KIND>
+template <int KIND, bool ATLAS>
 __global__ void __launch_bounds__(kShadeBlock) __attribute__((amdgpu_waves_per_eu(KIND == MI355PT_MTL_STANDARD ? PT_SHADE_WAVES_STD : PT_SHADE_WAVES, 8)))
 k_shade(DScene S, DCamera cam, DPaths P, Params prm, uint32_t bounce, uint32_t n0, uint32_t do_miss) {
     const uint32_t n = bounce == 0 ? n0 : P.counts[bounce];
@@ -871,7 +872,7 @@ k_shade(DScene S, DCamera cam, DPaths P, Params prm, uint32_t bounce, uint32_t n
                 F3 wo = -1.0f * r.d;
                 wo = wo / len(wo);
                 MatCtx m;
-                mat_prepare<KIND>(S, h, m);
+                mat_prepare<KIND, ATLAS>(S, h, m);
 #ifdef PT_SHADE_PROBE
                 asm volatile("" :: "v"(m.brdfN.x), "v"(h.p.x) : "memory");
                 PT_SHADE_TICK(pk_surf)
@@ -1185,7 +1186,7 @@ struct mi355pt_scene {
     std::vector<ptb::MeshTree> trees;
     DevBuf<DNodeXf> nodes; DevBuf<DInst> insts; DevBuf<DModel> models; DevBuf<DMesh> meshes;
     DevBuf<float4> bvh_nodes, tris, attrs, recs; DevBuf<uint32_t> faces; DevBuf<float> normals, uvw, tangents, bitangents;
-    DevBuf<mi355pt_material> materials; DevBuf<mi355pt_texmap> texmaps; DevBuf<DTexture> textures; DevBuf<DLight> lights; DevBuf<float> light_data;
+    DevBuf<mi355pt_material> materials; DevBuf<mi355pt_texmap> texmaps; DevBuf<DTexture> textures; DevBuf<DAtlas> atlases; DevBuf<int> mtl_atlas; DevBuf<DLight> lights; DevBuf<float> light_data;
     bool model_lights = false;        // some light sits on a Model: its own-object test is a BVH traversal (k_trace<2>)
     uint32_t mtl_kinds = 0;           // bit 0: some material is Disney, bit 1: some is Cook-Torrance ("standard")
     // Renderers keep a pointer to their scene: scene_destroy while some are alive only marks the scene, and the last
@@ -1554,17 +1555,54 @@ int mi355pt_scene_create(const mi355pt_scene_desc* desc, int32_t device, mi355pt
             HIP_TRY(hipMemcpy(p, px.data(), n * sizeof(float4), hipMemcpyHostToDevice)); d.data = p;
         } else if (s.kind != MI355PT_TEX_CHECKER) { d.width = d.height = 0; }
     }
+    // ---- material atlases (DAtlas, pt_scene.h): four 8-bit maps of one size under one texture transform -> one 8-B-per-texel copy
+    std::vector<DAtlas> atlases; std::vector<int> mtl_atlas(materials.size(), -1);
+    if (!getenv("MI355PT_NO_ATLAS")) {
+        std::vector<std::array<int, 4>> keys;
+        for (size_t mi = 0; mi < materials.size(); mi++) {
+            const mi355pt_material& m = materials[mi];
+            const int maps[4] = {m.albedo_map, m.normal_map, m.roughness_map, m.metalness_map};
+            std::array<int, 4> tex{}; bool ok = true;
+            for (int k = 0; k < 4 && ok; k++) {
+                ok = maps[k] >= 0 && texmaps[maps[k]].texture >= 0;
+                if (!ok) break;
+                tex[k] = texmaps[maps[k]].texture;
+                const mi355pt_texture& t = desc->textures[tex[k]], &t0 = desc->textures[tex[0]];
+                ok = t.kind == MI355PT_TEX_RGB8 && t.data && t.width > 0 && t.height > 0 && t.width == t0.width && t.height == t0.height &&
+                     !memcmp(texmaps[maps[k]].itm, texmaps[maps[0]].itm, sizeof(texmaps[0].itm)) && !memcmp(texmaps[maps[k]].pos, texmaps[maps[0]].pos, sizeof(texmaps[0].pos));
+            }
+            if (!ok) continue;
+            size_t found = 0;
+            for (; found < keys.size(); found++) if (keys[found] == tex) break;
+            if (found == keys.size()) {
+                const mi355pt_texture& t0 = desc->textures[tex[0]];
+                const size_t n = (size_t)t0.width * t0.height;
+                const uint8_t* a = (const uint8_t*)desc->textures[tex[0]].data; const uint8_t* nm = (const uint8_t*)desc->textures[tex[1]].data;
+                const uint8_t* ro = (const uint8_t*)desc->textures[tex[2]].data; const uint8_t* me = (const uint8_t*)desc->textures[tex[3]].data;
+                std::vector<uint2> px(n);
+                for (size_t k = 0; k < n; k++)
+                    px[k] = make_uint2((uint32_t)a[3 * k] | (uint32_t)a[3 * k + 1] << 8 | (uint32_t)a[3 * k + 2] << 16 | (uint32_t)nm[3 * k] << 24,
+                                       (uint32_t)nm[3 * k + 1] | (uint32_t)nm[3 * k + 2] << 8 | (uint32_t)ro[3 * k] << 16 | (uint32_t)me[3 * k] << 24);
+                void* p; HIP_TRY(hipMalloc(&p, n * sizeof(uint2))); sc->tex_data.push_back(p);
+                HIP_TRY(hipMemcpy(p, px.data(), n * sizeof(uint2), hipMemcpyHostToDevice));
+                DAtlas A; A.width = t0.width; A.height = t0.height; A.data = (const uint2*)p;
+                atlases.push_back(A); keys.push_back(tex);
+            }
+            mtl_atlas[mi] = (int)found;
+        }
+    }
     // ---- upload
     HIP_TRY(sc->nodes.upload(nodes)); HIP_TRY(sc->insts.upload(insts)); HIP_TRY(sc->models.upload(models)); HIP_TRY(sc->meshes.upload(meshes));
     HIP_TRY(sc->bvh_nodes.upload(bvh_nodes)); HIP_TRY(sc->tris.upload(tris)); HIP_TRY(sc->attrs.upload(attrs)); HIP_TRY(sc->faces.upload(faces));
     HIP_TRY(sc->normals.upload(normals)); HIP_TRY(sc->uvw.upload(uvw)); HIP_TRY(sc->tangents.upload(tangents)); HIP_TRY(sc->bitangents.upload(bitangents));
     HIP_TRY(sc->recs.upload(recs));
-    HIP_TRY(sc->materials.upload(materials)); HIP_TRY(sc->texmaps.upload(texmaps)); HIP_TRY(sc->textures.upload(textures)); HIP_TRY(sc->lights.upload(lights)); HIP_TRY(sc->light_data.upload(light_data));
+    HIP_TRY(sc->materials.upload(materials)); HIP_TRY(sc->texmaps.upload(texmaps)); HIP_TRY(sc->textures.upload(textures)); HIP_TRY(sc->lights.upload(lights));
+    if (!atlases.empty()) { HIP_TRY(sc->atlases.upload(atlases)); HIP_TRY(sc->mtl_atlas.upload(mtl_atlas)); } HIP_TRY(sc->light_data.upload(light_data));
     DScene& d = sc->d;
     d.nodes = sc->nodes.p; d.num_nodes = (int)nodes.size(); d.insts = sc->insts.p; d.num_insts = (int)insts.size();
     d.models = sc->models.p; d.meshes = sc->meshes.p; d.bvh_nodes = sc->bvh_nodes.p; d.tris = sc->tris.p; d.attrs = sc->attrs.p; d.faces = sc->faces.p;
     d.normals = sc->normals.p; d.uvw = sc->uvw.p; d.tangents = sc->tangents.p; d.bitangents = sc->bitangents.p;
-    d.materials = sc->materials.p; d.texmaps = sc->texmaps.p; d.textures = sc->textures.p; d.lights = sc->lights.p; d.num_lights = (int)lights.size(); d.light_data = sc->light_data.p;
+    d.materials = sc->materials.p; d.texmaps = sc->texmaps.p; d.textures = sc->textures.p; d.mtl_atlas = atlases.empty() ? nullptr : sc->mtl_atlas.p; d.atlases = atlases.empty() ? nullptr : sc->atlases.p; d.lights = sc->lights.p; d.num_lights = (int)lights.size(); d.light_data = sc->light_data.p;
     d.plane_lights_only = 1;
     for (const DLight& L : lights) if (L.kind != MI355PT_OBJ_PLANE) d.plane_lights_only = 0;
     d.recs = sc->recs.p; d.num_recs = (int)(recs.size() / kRecStride);
@@ -1889,8 +1927,15 @@ int run_paths(mi355pt_render* r, uint32_t n, uint32_t jitter = 1, uint32_t only_
         ev_begin(r, 1, r->stream);
         // one launch per material model present in the scene (k_shade<KIND>); the first one also finishes the misses
         const uint32_t kinds = r->scene->mtl_kinds ? r->scene->mtl_kinds : 1u;
-        if (kinds & 1u) hipLaunchKernelGGL(k_shade<MI355PT_MTL_DISNEY>, dim3(gs), dim3(kShadeBlock), 0, r->stream, S, r->cam, P, prm, b, n, 1u);
-        if (kinds & 2u) hipLaunchKernelGGL(k_shade<MI355PT_MTL_STANDARD>, dim3(gs), dim3(kShadeBlock), 0, r->stream, S, r->cam, P, prm, b, n, (kinds & 1u) ? 0u : 1u);
+        // (... and per "the scene has material atlases": the instances without that code keep their registers)
+        const uint32_t miss2 = (kinds & 1u) ? 0u : 1u;
+        if (S.mtl_atlas) {
+            if (kinds & 1u) hipLaunchKernelGGL((k_shade<MI355PT_MTL_DISNEY, true>), dim3(gs), dim3(kShadeBlock), 0, r->stream, S, r->cam, P, prm, b, n, 1u);
+            if (kinds & 2u) hipLaunchKernelGGL((k_shade<MI355PT_MTL_STANDARD, true>), dim3(gs), dim3(kShadeBlock), 0, r->stream, S, r->cam, P, prm, b, n, miss2);
+        } else {
+            if (kinds & 1u) hipLaunchKernelGGL((k_shade<MI355PT_MTL_DISNEY, false>), dim3(gs), dim3(kShadeBlock), 0, r->stream, S, r->cam, P, prm, b, n, 1u);
+            if (kinds & 2u) hipLaunchKernelGGL((k_shade<MI355PT_MTL_STANDARD, false>), dim3(gs), dim3(kShadeBlock), 0, r->stream, S, r->cam, P, prm, b, n, miss2);
+        }
         ev_end(r, r->stream);
         // the next bounce's closest-hit trace is enqueued BEFORE this bounce's visibility trace: it is the critical path,
         // and the kernel that is dispatched first fills the chip first

@@ -28,6 +28,11 @@ struct DMesh {
     uint32_t has_tangents, pad;
 };
 struct DTexture { int kind, width, height, pad; const void* data; float c1[3], c2[3]; };
+// A material whose four maps (albedo, normal, roughness, metalness) are 8-bit images of one size under one texture
+// transform gets a fused copy of them, 8 B per texel: albedo RGB, normal RGB, roughness R, metalness R (the scalar maps
+// are read through `.x` only).  The four lookups of a vertex then share their coordinates, weights and cache lines;
+// the values and the arithmetic per channel are those of the separate lookups.
+struct DAtlas { int width, height; const uint2* data; };
 // rec / rec_end: the walk records of the light's object.  Model lights: `data` indexes DScene::light_data, which holds
 // Model::cdf->cd (n_cd partial sums, the first 0) and then the three vertices of face 0 of every mesh (9 floats each).
 struct DLight { int node; float intensity[3]; float area; int inst; int rec; int rec_end; int kind; int data; int n_cd; int pad; };
@@ -63,6 +68,8 @@ struct DScene {
     const mi355pt_material* materials;
     const mi355pt_texmap*   texmaps;
     const DTexture* textures;
+    const int*      mtl_atlas;       // per material: index into atlases, -1 = none; nullptr when the scene has no atlas
+    const DAtlas*   atlases;
     const DLight*   lights;     int num_lights;
     const float*    light_data;
     int             plane_lights_only;   // every light sits on a Plane: the kernels take the short analytic path (uniform branch)

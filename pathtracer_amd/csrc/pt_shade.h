@@ -219,6 +219,48 @@ PT_DEV F3 texmap_sample(const DScene& S, int map, F3 uvw, F3 d0, F3 d1) {
     const F3 e1 = m3mul(m.itm, (d1 + uvw) - pos) - u;
     return tex_filtered(S, S.textures[m.texture], u, e0, e1);
 }
+// The four maps of a material from its atlas (DAtlas): tex_point / tex_filtered / texmap_sample above, with the coordinates,
+// wrap and bilinear weights computed once per tap and eight channels accumulated instead of three.
+struct AtlasTaps { F3 alb, nrm; float rough, metal; };
+PT_DEV AtlasTaps atlas_point(const DAtlas& t, F3 uvw) {
+    const int width = t.width, height = t.height;
+    const F3 u = tile_clamp(uvw);
+    const float x = width * u.x, y = height * u.y;
+    int ix = (int)x, iy = (int)y;
+    const float fx = x - ix, fy = y - iy;
+    if (ix < 0) ix -= (ix / width - 1) * width;
+    if (ix >= width) ix -= (ix / width) * width;
+    int ixp = ix + 1; if (ixp >= width) ixp -= width;
+    if (iy < 0) iy -= (iy / height - 1) * height;
+    if (iy >= height) iy -= (iy / height) * height;
+    int iyp = iy + 1; if (iyp >= height) iyp -= height;
+    const uint2 t00 = t.data[(size_t)iy * width + ix], t01 = t.data[(size_t)iy * width + ixp];
+    const uint2 t10 = t.data[(size_t)iyp * width + ix], t11 = t.data[(size_t)iyp * width + ixp];
+    const float w00 = (1 - fx) * (1 - fy), w01 = fx * (1 - fy), w10 = (1 - fx) * fy, w11 = fx * fy;
+#define PT_AT(word, sh) (u8_unorm((t00.word >> sh) & 255u) * w00 + u8_unorm((t01.word >> sh) & 255u) * w01 + \
+                         u8_unorm((t10.word >> sh) & 255u) * w10 + u8_unorm((t11.word >> sh) & 255u) * w11)
+    AtlasTaps r;
+    r.alb = f3(PT_AT(x, 0), PT_AT(x, 8), PT_AT(x, 16));
+    r.nrm = f3(PT_AT(x, 24), PT_AT(y, 0), PT_AT(y, 8));
+    r.rough = PT_AT(y, 16); r.metal = PT_AT(y, 24);
+#undef PT_AT
+    return r;
+}
+PT_DEV AtlasTaps atlas_sample(const DScene& S, const DAtlas& t, const mi355pt_texmap& m, F3 uvw, F3 d0, F3 d1) {
+    const F3 pos = ld3(m.pos);
+    const F3 u = m3mul(m.itm, uvw - pos);
+    const F3 e0 = m3mul(m.itm, (d0 + uvw) - pos) - u;
+    const F3 e1 = m3mul(m.itm, (d1 + uvw) - pos) - u;
+    AtlasTaps c = atlas_point(t, u);
+    if (len2(e0) + len2(e1) == 0) return c;
+    for (int i = 1; i < 32; i++) {
+        const float x = S.filter_taps[2 * i], y = S.filter_taps[2 * i + 1];
+        const AtlasTaps p = atlas_point(t, u + x * e0 + y * e1);
+        c.alb = c.alb + p.alb; c.nrm = c.nrm + p.nrm; c.rough = c.rough + p.rough; c.metal = c.metal + p.metal;
+    }
+    c.alb = c.alb / 32.0f; c.nrm = c.nrm / 32.0f; c.rough = c.rough / 32.0f; c.metal = c.metal / 32.0f;
+    return c;
+}
 PT_DEV F3 textured_color(const DScene& S, const float* color, int map, const Surf& h) {
     const F3 c = ld3(color);
     return map >= 0 ? c * texmap_sample(S, map, h.uvw, h.du0, h.du1) : c;
@@ -432,34 +474,49 @@ struct MatCtx {
 };
 // KIND >= 0: the caller knows the material kind (k_shade<KIND> only takes hits of that kind): the other model's code, and
 // the registers its values would occupy, drop out at compile time.
-template <int KIND = -1>
+// ATLAS: the scene has material atlases (DScene::mtl_atlas); instances for scenes without one do not carry that code.
+template <int KIND = -1, bool ATLAS = true>
 PT_DEV void mat_prepare(const DScene& S, const Surf& h, MatCtx& m) {
     const mi355pt_material& mt = S.materials[h.mtl];
     m.kind = KIND >= 0 ? KIND : mt.kind;
     F3 N = h.N; N = N / len(N);
     m.Ngeo = N;
     m.brdfN = N;
-    if (mt.normal_map >= 0) {
-        const F3 c = texmap_sample(S, mt.normal_map, h.uvw, h.du0, h.du1);
-        const F3 tn = f3(2.0f * c.x - 1.0f, 2.0f * c.y - 1.0f, 2.0f * c.z - 1.0f);
+    const int atlas = (ATLAS && S.mtl_atlas) ? S.mtl_atlas[h.mtl] : -1;
+    F3 base; float rough, metal;                         // the three textured colours, the same lookups for both models
+    if (ATLAS && atlas >= 0) {                           // all four maps from one fused texture (DAtlas, pt_scene.h)
+        const AtlasTaps a = atlas_sample(S, S.atlases[atlas], S.texmaps[mt.albedo_map], h.uvw, h.du0, h.du1);
+        const F3 tn = f3(2.0f * a.nrm.x - 1.0f, 2.0f * a.nrm.y - 1.0f, 2.0f * a.nrm.z - 1.0f);
         F3 b = h.N * tn.z + normalized(h.B) * tn.y + normalized(h.T) * tn.x;
         m.brdfN = b / len(b);
+        base = ld3(mt.albedo) * f3(a_powf(a.alb.x, 2.2f), a_powf(a.alb.y, 2.2f), a_powf(a.alb.z, 2.2f));
+        rough = mt.roughness[0] * a.rough; metal = mt.metalness[0] * a.metal;
+    } else {
+        if (mt.normal_map >= 0) {
+            const F3 c = texmap_sample(S, mt.normal_map, h.uvw, h.du0, h.du1);
+            const F3 tn = f3(2.0f * c.x - 1.0f, 2.0f * c.y - 1.0f, 2.0f * c.z - 1.0f);
+            F3 b = h.N * tn.z + normalized(h.B) * tn.y + normalized(h.T) * tn.x;
+            m.brdfN = b / len(b);
+        }
+        base = textured_color_srgb(S, mt.albedo, mt.albedo_map, h);
+        rough = textured_color(S, mt.roughness, mt.roughness_map, h).x;
+        metal = textured_color(S, mt.metalness, mt.metalness_map, h).x;
     }
     m.emission = f3(0, 0, 0);
     if (m.kind == MI355PT_MTL_DISNEY) {
-        m.d.base = textured_color_srgb(S, mt.albedo, mt.albedo_map, h);
-        m.d.roughness = textured_color(S, mt.roughness, mt.roughness_map, h).x;
-        m.d.metallic = textured_color(S, mt.metalness, mt.metalness_map, h).x;
+        m.d.base = base;
+        m.d.roughness = rough;
+        m.d.metallic = metal;
         m.d.clearcoat = mt.clearcoat; m.d.clearcoatGloss = mt.clearcoat_gloss; m.d.sheen = mt.sheen; m.d.sheenTint = mt.sheen_tint;
         m.d.specular = mt.specular; m.d.specularTint = mt.specular_tint; m.d.subsurface = mt.subsurface;
         disney_finish(m.d);
         const int li = h.light;
         if (li >= 0) m.emission = ld3(S.lights[li].intensity);      // disneyMaterial.h:193-198
     } else {
-        m.albedo = textured_color_srgb(S, mt.albedo, mt.albedo_map, h);
-        m.rough_raw = textured_color(S, mt.roughness, mt.roughness_map, h).x;
+        m.albedo = base;
+        m.rough_raw = rough;
         m.rough_eval = m.rough_raw <= 0.0f ? 0.001f : m.rough_raw;
-        m.metal = textured_color(S, mt.metalness, mt.metalness_map, h).x;
+        m.metal = metal;
     }
 }
 PT_DEV float mat_pdf(const MatCtx& m, F3 wi, F3 wo) {

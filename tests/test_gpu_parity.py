@@ -572,3 +572,43 @@ def test_c2_with_1024_png_maps(tmp_path):
     pt.step(1); pt.sync()
     assert pt.stats()["texture_taps"] > 32 * 4 * 1000            # filtered lookups really ran
     pt.close_render()
+
+
+def test_material_atlas_same_results(built, monkeypatch):
+    """A material whose four 8-bit maps share size and texture transform is sampled from one fused 8-B-per-texel copy
+    (DAtlas, pt_scene.h): same coordinates, weights and per-channel arithmetic, a quarter of the fetches.  With the atlas
+    switched off (MI355PT_NO_ATLAS, read at scene creation) every accumulator bit and every per-sample radiance is the same;
+    the scene also holds a material without maps, and the second scene's maps differ in their transforms (no atlas there)."""
+    from pathtracer_amd import DeviceScene
+    s, orc, pt, w, h = built("textured_c2")
+    rng = np.random.default_rng(17)
+    pixel = rng.integers(0, w * h, 4000).astype(np.uint32)
+    sample = rng.integers(0, 32, 4000).astype(np.uint32)
+    a, _ = pt.sample_radiance(pixel, sample)
+    pt.Init(w, h); pt.step(3); pt.sync()
+    ma, ca = pt.read_accum()
+    monkeypatch.setenv("MI355PT_NO_ATLAS", "1")
+    ds = DeviceScene(s)
+    p2 = PathTracer(ds)
+    p2.Init(w, h)
+    b, _ = p2.sample_radiance(pixel, sample)
+    p2.step(3); p2.sync()
+    mb, cb = p2.read_accum()
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    assert np.array_equal(ma.view(np.uint32), mb.view(np.uint32)) and np.array_equal(ca, cb)
+    assert p2.stats()["texture_taps"] > 0 and pt.stats()["texture_taps"] > 0
+    p2.close_render()
+    monkeypatch.delenv("MI355PT_NO_ATLAS")
+    # maps of one size under DIFFERENT transforms must stay on the separate path: against the oracle
+    from oracle.binding import OracleScene
+    from pathtracer_amd import scenes
+    s2 = scenes.textured_c2(w, h, tex_size=64)
+    s2.materials[0].normal_map.Scale(1.5)
+    s2.materials[1].roughness_map.Translate((0.25, 0.0, 0.0))
+    p3 = PathTracer(s2)
+    p3.Init(w, h)
+    lin, _ = p3.sample_radiance(pixel, sample)
+    olin, _ = OracleScene(s2).sample_radiance(p3.params, pixel, sample)
+    frac, _ = common.radiance_agreement(lin, olin)
+    assert frac >= 0.999
+    p3.close_render()
