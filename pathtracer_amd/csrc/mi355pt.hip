@@ -65,7 +65,7 @@ struct DPaths {
     uint32_t *spill;      // per resident wave: kStackSize x 64 dwords, the part of a lane's stack below its LDS window
     uint32_t *spill_any;  // the same for k_trace<ANY>, which may run beside k_trace<closest> of the next bounce
     unsigned long long *stat;   // [0] closest rays [1] shadow rays [2] samples [3,4] extend node visits / tri tests [5,6] visibility ditto [7] guard
-                                // [8..15] counting builds' diagnostics [16] vertices shaded [17] bilinear texture lookups
+                                // [8..15] counting builds' diagnostics [16] vertices shaded [17] bilinear texture lookups [18] rays bounce 0's pre-pass finished in the current run
 };
 struct Params { uint32_t seed, width, height, max_bounces, rr_start, stack_entries, node_lanes, owner_lanes, gen, use_prep, no_cull, ntop; };
 
@@ -108,7 +108,8 @@ __device__ __forceinline__ uint32_t xcd_block(uint32_t b, uint32_t nb) {
 }
 
 // One ray of k_prepare (below): the object walk up to the first mesh `wr` must traverse.
-__device__ __forceinline__ void prepare_ray(const DScene& S, const DPaths& P, uint32_t slot, Ray wr) {
+// Returns true when the ray was finished here (no mesh in its way).
+__device__ __forceinline__ bool prepare_ray(const DScene& S, const DPaths& P, uint32_t slot, Ray wr) {
     if (S.num_recs > 0) wr = rec_ray(S, S.recs, 1u, 0u, wr);
     float best_t = kBig; int best_inst = -1;
     uint32_t rec = 0;
@@ -154,6 +155,16 @@ __device__ __forceinline__ void prepare_ray(const DScene& S, const DPaths& P, ui
         store_hit(P, slot, best_t, best_inst, -1, 0u);
         A[2] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(0xFFFFFFFFu));
     }
+    return !found;
+}
+// How long the pre-pass pays depends on the scene.  Where most camera rays never reach a mesh (C2: a floor, two models) it
+// finishes them with every lane busy and is worth its launch for every bounce the host enables it for; where nearly every
+// ray enters the mesh (C4) it only moves the set-up, and pays for the two largest queues only (C4: 2 bounces 3 465 Mrays/s,
+// 5 bounces 3 407; C2: 5 bounces 3 238, 2 bounces 3 197, none 2 870).  Bounce 0's pass, inside k_init, counts the rays it
+// finished (stat[18]); k_prepare and k_trace<closest> of the later bounces read that count and decide alike.
+constexpr uint32_t kPrepAlways = 2;           // bounces that take the pre-pass whatever the scene
+__device__ __forceinline__ bool prep_active(const DPaths& P, uint32_t bounce, uint32_t n0) {
+    return bounce < kPrepAlways || 2ull * P.stat[18] > (unsigned long long)n0;
 }
 
 // ---------------------------------------------------------------------- init
@@ -175,6 +186,7 @@ __global__ void __launch_bounds__(kBlock) k_init(DPaths P, Params prm, uint32_t 
                                                  const uint32_t* cnt, uint32_t sample_offset, uint32_t sample_stride,
                                                  const uint32_t* list_pix, const uint32_t* list_smp, const uint32_t* own,
                                                  DCamera cam, uint32_t with_rays, DScene S) {
+    unsigned long long fin = 0;                                 // rays the pre-pass finished (prep_active)
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         uint32_t pixel, sample;
         if (list_pix) { pixel = list_pix[i]; sample = list_smp[i]; }
@@ -191,9 +203,10 @@ __global__ void __launch_bounds__(kBlock) k_init(DPaths P, Params prm, uint32_t 
             Ray r; F3 rd, td;
             camera_rays(cam, prm.seed, pixel, sample, prm.width, true, r, rd, td);
             P.ray[2 * (size_t)i] = f4(r.p, 0.0f); P.ray[2 * (size_t)i + 1] = f4(r.d, 0.0f);
-            if (with_rays == 2u) prepare_ray(S, P, i, r);       // bounce 0's set-up pre-pass in the same pass (k_prepare)
+            if (with_rays == 2u && prepare_ray(S, P, i, r)) fin++;       // bounce 0's set-up pre-pass in the same pass (k_prepare)
         }
     }
+    if (with_rays == 2u) wave_add64(fin, &P.stat[18]);
 }
 
 // ---------------------------------------------------------------------- ray generation
@@ -280,6 +293,7 @@ __device__ __forceinline__ float key_dist(unsigned long long k) { return (k & 1u
 // root entry.  A ray with no mesh in its way is finished here (its hit record is written, record = 0xFFFFFFFF).
 // k_trace<0> (Params::use_prep) picks the ray up at that mesh; the walk behind it stays in the traversal kernel.
 __global__ void __launch_bounds__(kBlock) k_prepare(DScene S, DPaths P, uint32_t bounce, uint32_t n0) {
+    if (!prep_active(P, bounce, n0)) return;
     const uint32_t n = bounce == 0 ? n0 : P.counts[bounce];
     const uint32_t* q = bounce == 0 ? nullptr : P.queue[bounce & 1];
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
@@ -302,6 +316,7 @@ __global__ void __launch_bounds__(kExtBlockMax) k_trace(DScene S, DPaths P, Para
     const uint32_t n = MODE ? (uint32_t)(P.svcounts[bounce] >> 32) : (bounce == 0 ? n0 : P.counts[bounce]);
     const uint32_t* q = MODE ? P.vqueue : (bounce == 0 ? nullptr : P.queue[bounce & 1]);
     uint32_t* work = OWN ? &P.lwork[bounce] : ANY ? &P.vwork[bounce] : &P.work[bounce];
+    const bool use_prep = MODE == 0 && prm.use_prep && prep_active(P, bounce, n0);
     extern __shared__ uint32_t sm[];
     // A workgroup is `wpb` waves that never synchronise with each other after the set-up barrier: each wave is a persistent
     // worker with its own LDS area; the workgroup exists to SHARE one LDS copy of the walk records and of the top of the BVH.
@@ -409,7 +424,7 @@ __global__ void __launch_bounds__(kExtBlockMax) k_trace(DScene S, DPaths P, Para
                         if (idx < pool_end) {
                             slot = q ? q[idx] : idx;
                             rec = 0; state = LS_SETUP;
-                            if (MODE == 0 && prm.use_prep) {                  // k_prepare has walked this ray up to its first mesh
+                            if (MODE == 0 && use_prep) {                      // k_prepare has walked this ray up to its first mesh
                                 const float4* A = P.prep + 4 * (size_t)slot;
                                 const float4 a0 = A[0], a1 = A[1], a2 = A[2], a3 = A[3];
                                 rec = __float_as_uint(a2.w);
@@ -1983,6 +1998,7 @@ int mi355pt_render_step(mi355pt_render* r, uint32_t spp) {
             const uint32_t ns = (uint32_t)std::min<size_t>(spc, spp - s0);
             const uint32_t n = np * ns;
             ev_begin(r, 3, r->stream);
+            HIP_TRY(hipMemsetAsync(r->P.stat + 18, 0, sizeof(unsigned long long), r->stream));     // prep_active's count of this run
             hipLaunchKernelGGL(k_init, dim3(grid_for(r, n)), dim3(kBlock), 0, r->stream, r->P, kprm,
                                n, (uint32_t)pix_base, np, r->slot_group, r->cnt, p.sample_offset, p.sample_stride, (const uint32_t*)nullptr, (const uint32_t*)nullptr, (const uint32_t*)r->own, r->cam, use_prepass(r, n) ? 2u : 1u, r->scene->d);
             ev_end(r, r->stream);
@@ -2145,6 +2161,7 @@ int mi355pt_sample_radiance(mi355pt_render* r, const uint32_t* pixel, const uint
     HIP_TRY(hipMemcpy(dp, pixel, (size_t)count * 4, hipMemcpyHostToDevice)); HIP_TRY(hipMemcpy(ds, sample, (size_t)count * 4, hipMemcpyHostToDevice));
     const mi355pt_render_params& p = r->prm;
     const Params kprm{p.seed, p.width, p.height, p.max_bounces, p.rr_start, r->stack_entries, r->node_lanes, r->owner_lanes};
+    HIP_TRY(hipMemsetAsync(r->P.stat + 18, 0, sizeof(unsigned long long), r->stream));
     hipLaunchKernelGGL(k_init, dim3(grid_for(r, count)), dim3(kBlock), 0, r->stream, r->P, kprm,
                        count, 0u, 1u, 0u, (const uint32_t*)r->cnt, 0u, 1u, (const uint32_t*)dp, (const uint32_t*)ds, (const uint32_t*)nullptr, r->cam, use_prepass(r, count) ? 2u : 1u, r->scene->d);
     const int rc = run_paths(r, count, 2u, 0u, use_prepass(r, count));
