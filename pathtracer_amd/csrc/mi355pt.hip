@@ -823,7 +823,7 @@ k_shade(DScene S, DCamera cam, DPaths P, Params prm, uint32_t bounce, uint32_t n
     uint32_t nh = 0;                                              // hits waiting in LDS (wave-uniform)
     uint32_t i0 = blockIdx.x * 64u;
 #ifdef PT_SHADE_PROBE     // where a wave's time goes (tools/shade_probe.py): gather / loads + surface + material / the rest
-    long long pk_t = clock64(), pk_gather = 0, pk_surf = 0, pk_rest = 0;
+    long long pk_t = clock64(), pk_gather = 0, pk_load = 0, pk_surf = 0, pk_rest = 0;
 #define PT_SHADE_TICK(acc) { const long long t_ = clock64(); acc += t_ - pk_t; pk_t = t_; }
 #else
 #define PT_SHADE_TICK(acc)
@@ -879,6 +879,10 @@ k_shade(DScene S, DCamera cam, DPaths P, Params prm, uint32_t bounce, uint32_t n
                 }
             }
             F3 T = xyz(P.T[slot]), C = xyz(P.C[slot]);
+#ifdef PT_SHADE_PROBE     // the path state has arrived
+            asm volatile("" :: "v"(T.x), "v"(C.x), "v"(r.d.x), "v"(hr.t), "v"(id.z) : "memory");
+            PT_SHADE_TICK(pk_load)
+#endif
             {
                 Surf h;
                 surf_from_hit(S, hr, r, hasDiff, rd, td, h);
@@ -989,7 +993,7 @@ k_shade(DScene S, DCamera cam, DPaths P, Params prm, uint32_t bounce, uint32_t n
     wave_add64(mis_blocked, &P.stat[1]);
     wave_add64(n_vert, &P.stat[16]); wave_add64(n_taps, &P.stat[17]);
 #ifdef PT_SHADE_PROBE
-    if (threadIdx.x == 0) { atomicAdd(&P.stat[8], (unsigned long long)pk_gather); atomicAdd(&P.stat[9], (unsigned long long)pk_surf); atomicAdd(&P.stat[10], (unsigned long long)pk_rest); }
+    if (threadIdx.x == 0) { atomicAdd(&P.stat[8], (unsigned long long)pk_gather); atomicAdd(&P.stat[9], (unsigned long long)pk_surf); atomicAdd(&P.stat[10], (unsigned long long)pk_rest); atomicAdd(&P.stat[11], (unsigned long long)pk_load); }
 #endif
 }
 

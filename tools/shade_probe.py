@@ -15,7 +15,7 @@ pt.reset_stats()
 pt.set_profiling(2, False)
 pt.render(spp)
 st = pt.stats()
-g, s, r = st["debug"][0:3]
-tot = g + s + r
-print(f"{wl}: shade {st['shade_ms']:.2f} ms per step; wave time: gather {g / tot:.3f}, loads+surface+material {s / tot:.3f}, sampling/eval/outputs {r / tot:.3f}; "
+g, s, r, l = st["debug"][0:4]
+tot = g + s + r + l
+print(f"{wl}: shade {st['shade_ms']:.2f} ms per step; wave time: gather {g / tot:.3f}, path-state loads {l / tot:.3f}, surface+material {s / tot:.3f}, sampling/eval/outputs {r / tot:.3f}; "
       f"vertices {st['shaded_vertices']}")
