@@ -784,9 +784,30 @@ constexpr int kShadeBlock = 64;
 // KIND: the material model this instance shades (MI355PT_MTL_DISNEY / _STANDARD: two code bodies, disneyMaterial.h:85-203 and
 // standardMaterial.h:33-103): hits on the other kind are left to the other instance's launch, and only the instance with
 // `do_miss` finishes the misses.  A scene with one kind of material runs one instance.
-template <int KIND, bool ATLAS>
+template <int KIND, bool ATLAS, bool TABLES>
 __global__ void __launch_bounds__(kShadeBlock) __attribute__((amdgpu_waves_per_eu(KIND == MI355PT_MTL_STANDARD ? PT_SHADE_WAVES_STD : PT_SHADE_WAVES, 8)))
-k_shade(DScene S, DCamera cam, DPaths P, Params prm, uint32_t bounce, uint32_t n0, uint32_t do_miss) {
+k_shade(DScene S, DCamera cam, DPaths P, Params prm, uint32_t bounce, uint32_t n0, uint32_t do_miss, uint32_t lds_tables) {
+    // The way from a hit record to its surface is a chain of dependent per-lane loads from small tables: instance -> node chain
+    // (level by level, into the object and back) -> material -> light.  They are cached, but a vector load that hits L1 still
+    // takes several hundred cycles and this kernel has two waves per SIMD to hide them: a third of the wave time on the
+    // all-analytic C3 went there.  Scenes whose tables fit (shade_table_bytes) and whose materials have no maps get a copy
+    // in LDS per workgroup: C4 3 470 -> 3 555 Mrays/s, C3 9 830 -> 10 360, C1 unchanged; the textured C2 lost 4 % with it
+    // (with or without the materials in the copy), hence the second condition.
+    // (TABLES is a template parameter: pointers that MAY point into LDS turn every access through them into a flat load,
+    // which cost the textured C2 15 % even with the copy switched off at run time.)
+    extern __shared__ float4 tables[];
+    if (TABLES && lds_tables) {
+        const uint32_t ni = (uint32_t)S.num_insts * (uint32_t)sizeof(DInst) / 16u, nn = ((uint32_t)S.num_nodes * (uint32_t)sizeof(DNodeXf) + 15u) / 16u;
+        const uint32_t nm = ((uint32_t)S.num_materials * (uint32_t)sizeof(mi355pt_material) + 15u) / 16u, nl = (uint32_t)S.num_lights * (uint32_t)sizeof(DLight) / 16u;
+        for (uint32_t k = threadIdx.x; k < ni; k += 64u) tables[k] = ((const float4*)S.insts)[k];
+        for (uint32_t k = threadIdx.x; k < nn; k += 64u) tables[ni + k] = ((const float4*)S.nodes)[k];
+        for (uint32_t k = threadIdx.x; k < nm; k += 64u) tables[ni + nn + k] = ((const float4*)S.materials)[k];
+        for (uint32_t k = threadIdx.x; k < nl; k += 64u) tables[ni + nn + nm + k] = ((const float4*)S.lights)[k];
+        __syncthreads();
+        S.insts = (const DInst*)tables; S.nodes = (const DNodeXf*)(tables + ni);
+        S.materials = (const mi355pt_material*)(tables + ni + nn);
+        S.lights = (const DLight*)(tables + ni + nn + nm);
+    }
     const uint32_t n = bounce == 0 ? n0 : P.counts[bounce];
     const uint32_t* q = bounce == 0 ? nullptr : P.queue[bounce & 1];
     uint32_t* qnext = P.queue[(bounce + 1) & 1];
@@ -1165,6 +1186,17 @@ __global__ void __launch_bounds__(kBlock) k_static_out(DScene S, DPaths P, uint3
 // ====================================================================== host side
 namespace {
 
+static_assert(sizeof(DInst) % 16 == 0 && sizeof(DLight) % 16 == 0, "k_shade copies these tables to LDS in 16-B pieces");
+// LDS bytes of k_shade's table copy (instances, nodes, materials, lights), 0 when the scene's tables are too large for it.
+// The copies round up to 16 B and may read up to 12 B past the node / material arrays: DevBuf allocations are padded.
+uint32_t shade_table_bytes(const DScene& S, bool any_maps) {
+    if (any_maps) return 0u;
+    const size_t b = (size_t)S.num_insts * sizeof(DInst) + (((size_t)S.num_nodes * sizeof(DNodeXf) + 15) & ~(size_t)15) +
+                     (((size_t)S.num_materials * sizeof(mi355pt_material) + 15) & ~(size_t)15) + (size_t)S.num_lights * sizeof(DLight);
+    static const bool off = getenv("MI355PT_NO_SHADE_TABLES") != nullptr;
+    return (!off && b <= 12288) ? (uint32_t)b : 0u;
+}
+
 thread_local std::string g_err;
 int fail(int code, const std::string& msg) { g_err = msg; return code; }
 #define HIP_TRY(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return fail(MI355PT_ERR_HIP, std::string(#x) + ": " + hipGetErrorString(e_)); } while (0)
@@ -1172,7 +1204,7 @@ int fail(int code, const std::string& msg) { g_err = msg; return code; }
 template <typename T>
 struct DevBuf {
     T* p = nullptr; size_t n = 0;
-    hipError_t alloc(size_t count) { n = count; return hipMalloc((void**)&p, std::max<size_t>(count, 1) * sizeof(T)); }
+    hipError_t alloc(size_t count) { n = count; return hipMalloc((void**)&p, std::max<size_t>(count, 1) * sizeof(T) + 16); }     // + 16: k_shade's table copy reads whole 16-B pieces
     hipError_t upload(const std::vector<T>& v) {
         hipError_t e = alloc(v.size()); if (e != hipSuccess) return e;
         if (!v.empty()) e = hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice);
@@ -1208,6 +1240,7 @@ struct mi355pt_scene {
     DevBuf<mi355pt_material> materials; DevBuf<mi355pt_texmap> texmaps; DevBuf<DTexture> textures; DevBuf<DAtlas> atlases; DevBuf<int> mtl_atlas; DevBuf<DLight> lights; DevBuf<float> light_data;
     bool model_lights = false;        // some light sits on a Model: its own-object test is a BVH traversal (k_trace<2>)
     uint32_t mtl_kinds = 0;           // bit 0: some material is Disney, bit 1: some is Cook-Torrance ("standard")
+    bool any_maps = false;            // some material has a texture map (k_shade then keeps its tables in global memory)
     // Renderers keep a pointer to their scene: scene_destroy while some are alive only marks the scene, and the last
     // render_destroy frees it (a reference maintainer's Restart() tears things down in whatever order it likes).
     std::mutex life; int renderers = 0; bool doomed = false;
@@ -1551,6 +1584,7 @@ int mi355pt_scene_create(const mi355pt_scene_desc* desc, int32_t device, mi355pt
     for (auto& m : materials) {
         if (m.kind != MI355PT_MTL_DISNEY && m.kind != MI355PT_MTL_STANDARD) return fail(MI355PT_ERR_UNSUPPORTED, "unknown material kind");
         sc->mtl_kinds |= m.kind == MI355PT_MTL_DISNEY ? 1u : 2u;
+        if (m.albedo_map >= 0 || m.roughness_map >= 0 || m.metalness_map >= 0 || m.normal_map >= 0) sc->any_maps = true;
     }
     auto bad_map = [&](int m) { return m >= (int)desc->num_texmaps; };
     for (auto& m : materials) if (bad_map(m.albedo_map) || bad_map(m.roughness_map) || bad_map(m.metalness_map) || bad_map(m.normal_map)) return fail(MI355PT_ERR_INVALID, "bad texmap index");
@@ -1621,7 +1655,7 @@ int mi355pt_scene_create(const mi355pt_scene_desc* desc, int32_t device, mi355pt
     d.nodes = sc->nodes.p; d.num_nodes = (int)nodes.size(); d.insts = sc->insts.p; d.num_insts = (int)insts.size();
     d.models = sc->models.p; d.meshes = sc->meshes.p; d.bvh_nodes = sc->bvh_nodes.p; d.tris = sc->tris.p; d.attrs = sc->attrs.p; d.faces = sc->faces.p;
     d.normals = sc->normals.p; d.uvw = sc->uvw.p; d.tangents = sc->tangents.p; d.bitangents = sc->bitangents.p;
-    d.materials = sc->materials.p; d.texmaps = sc->texmaps.p; d.textures = sc->textures.p; d.mtl_atlas = atlases.empty() ? nullptr : sc->mtl_atlas.p; d.atlases = atlases.empty() ? nullptr : sc->atlases.p; d.lights = sc->lights.p; d.num_lights = (int)lights.size(); d.light_data = sc->light_data.p;
+    d.materials = sc->materials.p; d.num_materials = (int)materials.size(); d.texmaps = sc->texmaps.p; d.textures = sc->textures.p; d.mtl_atlas = atlases.empty() ? nullptr : sc->mtl_atlas.p; d.atlases = atlases.empty() ? nullptr : sc->atlases.p; d.lights = sc->lights.p; d.num_lights = (int)lights.size(); d.light_data = sc->light_data.p;
     d.plane_lights_only = 1;
     for (const DLight& L : lights) if (L.kind != MI355PT_OBJ_PLANE) d.plane_lights_only = 0;
     d.recs = sc->recs.p; d.num_recs = (int)(recs.size() / kRecStride);
@@ -1948,12 +1982,17 @@ int run_paths(mi355pt_render* r, uint32_t n, uint32_t jitter = 1, uint32_t only_
         const uint32_t kinds = r->scene->mtl_kinds ? r->scene->mtl_kinds : 1u;
         // (... and per "the scene has material atlases": the instances without that code keep their registers)
         const uint32_t miss2 = (kinds & 1u) ? 0u : 1u;
+        const uint32_t tb = shade_table_bytes(S, r->scene->any_maps);
+        auto shade = [&](auto kern, uint32_t miss) { hipLaunchKernelGGL(kern, dim3(gs), dim3(kShadeBlock), tb, r->stream, S, r->cam, P, prm, b, n, miss, tb); };
         if (S.mtl_atlas) {
-            if (kinds & 1u) hipLaunchKernelGGL((k_shade<MI355PT_MTL_DISNEY, true>), dim3(gs), dim3(kShadeBlock), 0, r->stream, S, r->cam, P, prm, b, n, 1u);
-            if (kinds & 2u) hipLaunchKernelGGL((k_shade<MI355PT_MTL_STANDARD, true>), dim3(gs), dim3(kShadeBlock), 0, r->stream, S, r->cam, P, prm, b, n, miss2);
+            if (kinds & 1u) shade(k_shade<MI355PT_MTL_DISNEY, true, false>, 1u);
+            if (kinds & 2u) shade(k_shade<MI355PT_MTL_STANDARD, true, false>, miss2);
+        } else if (tb) {
+            if (kinds & 1u) shade(k_shade<MI355PT_MTL_DISNEY, false, true>, 1u);
+            if (kinds & 2u) shade(k_shade<MI355PT_MTL_STANDARD, false, true>, miss2);
         } else {
-            if (kinds & 1u) hipLaunchKernelGGL((k_shade<MI355PT_MTL_DISNEY, false>), dim3(gs), dim3(kShadeBlock), 0, r->stream, S, r->cam, P, prm, b, n, 1u);
-            if (kinds & 2u) hipLaunchKernelGGL((k_shade<MI355PT_MTL_STANDARD, false>), dim3(gs), dim3(kShadeBlock), 0, r->stream, S, r->cam, P, prm, b, n, miss2);
+            if (kinds & 1u) shade(k_shade<MI355PT_MTL_DISNEY, false, false>, 1u);
+            if (kinds & 2u) shade(k_shade<MI355PT_MTL_STANDARD, false, false>, miss2);
         }
         ev_end(r, r->stream);
         // the next bounce's closest-hit trace is enqueued BEFORE this bounce's visibility trace: it is the critical path,

@@ -65,7 +65,7 @@ struct DScene {
     const float*    uvw;             // 3 per vertex
     const float*    tangents;        // 3 per face (indexed face_base + faceId)
     const float*    bitangents;
-    const mi355pt_material* materials;
+    const mi355pt_material* materials; int num_materials;
     const mi355pt_texmap*   texmaps;
     const DTexture* textures;
     const int*      mtl_atlas;       // per material: index into atlases, -1 = none; nullptr when the scene has no atlas
