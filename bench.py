@@ -217,6 +217,7 @@ def main():
         pt.sync()
         xs = pt.stats()
         pt.set_overlap(0)
+        out["kernel_ms_exclusive"] = {"extend": xs["extend_ms"], "shade": xs["shade_ms"], "visibility+connect": xs["connect_ms"], "other": xs["other_ms"], "steps": 1}
         pt.set_profiling(events=False, count_work=True)      # counting build, untimed
         pt.reset_stats()
         pt.step(spp_step)

@@ -1189,12 +1189,11 @@ namespace {
 static_assert(sizeof(DInst) % 16 == 0 && sizeof(DLight) % 16 == 0, "k_shade copies these tables to LDS in 16-B pieces");
 // LDS bytes of k_shade's table copy (instances, nodes, materials, lights), 0 when the scene's tables are too large for it.
 // The copies round up to 16 B and may read up to 12 B past the node / material arrays: DevBuf allocations are padded.
-uint32_t shade_table_bytes(const DScene& S, bool any_maps) {
-    if (any_maps) return 0u;
+uint32_t shade_table_bytes(const DScene& S, bool no_tables) {
+    if (no_tables) return 0u;
     const size_t b = (size_t)S.num_insts * sizeof(DInst) + (((size_t)S.num_nodes * sizeof(DNodeXf) + 15) & ~(size_t)15) +
                      (((size_t)S.num_materials * sizeof(mi355pt_material) + 15) & ~(size_t)15) + (size_t)S.num_lights * sizeof(DLight);
-    static const bool off = getenv("MI355PT_NO_SHADE_TABLES") != nullptr;
-    return (!off && b <= 12288) ? (uint32_t)b : 0u;
+    return b <= 12288 ? (uint32_t)b : 0u;
 }
 
 thread_local std::string g_err;
@@ -1241,6 +1240,7 @@ struct mi355pt_scene {
     bool model_lights = false;        // some light sits on a Model: its own-object test is a BVH traversal (k_trace<2>)
     uint32_t mtl_kinds = 0;           // bit 0: some material is Disney, bit 1: some is Cook-Torrance ("standard")
     bool any_maps = false;            // some material has a texture map (k_shade then keeps its tables in global memory)
+    bool no_shade_tables = false;     // MI355PT_NO_SHADE_TABLES at scene creation: the same for every scene (the A/B and test switch)
     // Renderers keep a pointer to their scene: scene_destroy while some are alive only marks the scene, and the last
     // render_destroy frees it (a reference maintainer's Restart() tears things down in whatever order it likes).
     std::mutex life; int renderers = 0; bool doomed = false;
@@ -1610,6 +1610,7 @@ int mi355pt_scene_create(const mi355pt_scene_desc* desc, int32_t device, mi355pt
     }
     // ---- material atlases (DAtlas, pt_scene.h): four 8-bit maps of one size under one texture transform -> one 8-B-per-texel copy
     std::vector<DAtlas> atlases; std::vector<int> mtl_atlas(materials.size(), -1);
+    sc->no_shade_tables = getenv("MI355PT_NO_SHADE_TABLES") != nullptr;
     if (!getenv("MI355PT_NO_ATLAS")) {
         std::vector<std::array<int, 4>> keys;
         for (size_t mi = 0; mi < materials.size(); mi++) {
@@ -1748,7 +1749,9 @@ int mi355pt_render_create(mi355pt_scene* scene, const mi355pt_render_params* par
     for (uint32_t b = 0; b < params->max_bounces; b++) {
         HIP_TRY(hipEventCreateWithFlags(&r->fork[b], hipEventDisableTiming)); HIP_TRY(hipEventCreateWithFlags(&r->join[b], hipEventDisableTiming));
     }
-    // from bounce 0 by default: each launch's thin tail is filled by the other stream's kernel (C4: 24.2 -> 22.0 ms per sample)
+    // from bounce 0 by default: each launch's thin tail is filled by the other stream's kernel (C4, one sample per step: 24.2 ->
+    // 22.0 ms per sample).  With 16-sample batches the tails are a small share: a step takes the sum of its kernels' exclusive
+    // times either way (195 ms) and the second stream only hides the ~6 ms of gaps between launches (200.7 -> 194.3 ms per step).
     r->overlap_from = 0;
     if (const char* e = getenv("MI355PT_OVERLAP_FROM")) r->overlap_from = (uint32_t)std::max(0, atoi(e));
     if (const char* e = getenv("MI355PT_SLOT_GROUP")) r->slot_group = (uint32_t)std::max(0, atoi(e));
@@ -1982,7 +1985,7 @@ int run_paths(mi355pt_render* r, uint32_t n, uint32_t jitter = 1, uint32_t only_
         const uint32_t kinds = r->scene->mtl_kinds ? r->scene->mtl_kinds : 1u;
         // (... and per "the scene has material atlases": the instances without that code keep their registers)
         const uint32_t miss2 = (kinds & 1u) ? 0u : 1u;
-        const uint32_t tb = shade_table_bytes(S, r->scene->any_maps);
+        const uint32_t tb = shade_table_bytes(S, r->scene->any_maps || r->scene->no_shade_tables);
         auto shade = [&](auto kern, uint32_t miss) { hipLaunchKernelGGL(kern, dim3(gs), dim3(kShadeBlock), tb, r->stream, S, r->cam, P, prm, b, n, miss, tb); };
         if (S.mtl_atlas) {
             if (kinds & 1u) shade(k_shade<MI355PT_MTL_DISNEY, true, false>, 1u);

@@ -612,3 +612,33 @@ def test_material_atlas_same_results(built, monkeypatch):
     frac, _ = common.radiance_agreement(lin, olin)
     assert frac >= 0.999
     p3.close_render()
+
+
+@pytest.mark.parametrize("name", ["teapot_cornell", "cornell_c1"])
+def test_shade_tables_in_lds_same_results(built, name, monkeypatch):
+    """k_shade<KIND, ATLAS, TABLES>: scenes without texture maps whose instance / node / material / light tables fit
+    12 KB get a copy of them in LDS per workgroup (the default here).  With MI355PT_NO_SHADE_TABLES (read at scene
+    creation) the instances that read the tables from global memory run: same per-sample radiance, same accumulators,
+    same ray counts, bit for bit."""
+    from pathtracer_amd import DeviceScene
+    s, orc, pt, w, h = built(name)
+    assert not any(m.albedo_map or m.normal_map or m.roughness_map or m.metalness_map for m in s.materials)
+    rng = np.random.default_rng(23)
+    pixel = rng.integers(0, w * h, 4000).astype(np.uint32)
+    sample = rng.integers(0, 32, 4000).astype(np.uint32)
+    a, _ = pt.sample_radiance(pixel, sample)
+    pt.Init(w, h); pt.step(3); pt.sync()
+    ma, ca = pt.read_accum()
+    sa = pt.stats()
+    monkeypatch.setenv("MI355PT_NO_SHADE_TABLES", "1")
+    p2 = PathTracer(DeviceScene(s))
+    monkeypatch.delenv("MI355PT_NO_SHADE_TABLES")
+    p2.Init(w, h)
+    b, _ = p2.sample_radiance(pixel, sample)
+    p2.Init(w, h); p2.step(3); p2.sync()
+    mb, cb = p2.read_accum()
+    sb = p2.stats()
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    assert np.array_equal(ma.view(np.uint32), mb.view(np.uint32)) and np.array_equal(ca, cb)
+    assert sb["shadow_rays"] > 0
+    p2.close_render()
