@@ -331,7 +331,7 @@ __global__ void __launch_bounds__(kExtBlockMax) k_trace(DScene S, DPaths P, Para
     unsigned long long* keyl = (unsigned long long*)(aux + kLdsKey);   // [64] best (t, slot) of the owner's current mesh
     uint32_t* nwork = aux + kLdsWork;                            // [64] lanes still walking for this owner
     uint32_t* xfer = aux + kLdsXfer;                             // [128] steal hand-over
-    uint8_t* tril = (uint8_t*)(aux + kLdsTri);                   // [256] expanded triangle list of one drain round
+    uint8_t* tril = (uint8_t*)(aux + kLdsTri);                   // [128 of 256] expanded triangle list of one drain pass: item << 2 | triangle
     // [64] per owner: the largest rounding-error bound of any candidate accepted for its ray so far (float bits; see
     // tri_closest_key).  A grazing hit's distance is noise of that size, and so is the distance the reference would
     // compute for its coplanar neighbours in other subtrees: the distance cull must keep that far behind the best.
@@ -395,7 +395,11 @@ __global__ void __launch_bounds__(kExtBlockMax) k_trace(DScene S, DPaths P, Para
     // counting builds: wave cycles per phase, passes, node-loop lanes (stats.debug, tools/diag_bounces.py)
     unsigned long long ck_setup = 0, ck_node = 0, ck_drain = 0, ck_rest = 0, n_node_it = 0, n_node_act = 0, n_drain_it = 0, n_drain_act = 0;
     unsigned long long ck0 = COUNT ? clock64() : 0;
+#ifdef PT_DIAG_BREAKS
+#define PT_PHASE(acc) do { } while (0)
+#else
 #define PT_PHASE(acc) do { if (COUNT) { const unsigned long long now_ = clock64(); acc += now_ - ck0; ck0 = now_; } } while (0)
+#endif
 
     for (;;) {
         // every pass makes progress (a node step, a drained queue, a finished mesh or a new ray), so a wave needs a few
@@ -586,6 +590,11 @@ __global__ void __launch_bounds__(kExtBlockMax) k_trace(DScene S, DPaths P, Para
                 const bool want = sp != sb;                             // only lanes in LS_TRAV / LS_THIEF have entries
                 const unsigned long long wm = __ballot(want);
                 const uint32_t nw = (uint32_t)__popcll(wm);
+#ifdef PT_DIAG_BREAKS
+                if (COUNT && (nw == 0 || (!first && nw < th) || kLeafQ - nq < 128u || it >= max_it)) {
+                    if (nw == 0) ck_setup++; else if (!first && nw < th) ck_node++; else if (kLeafQ - nq < 128u) ck_drain++; else ck_rest++;
+                }
+#endif
                 if (nw == 0 || (!first && nw < th) || kLeafQ - nq < 128u || it >= max_it) break;
                 first = false; it++;
                 if (COUNT) { n_node_it++; n_node_act += nw; }
@@ -657,18 +666,23 @@ __global__ void __launch_bounds__(kExtBlockMax) k_trace(DScene S, DPaths P, Para
         PT_PHASE(ck_node);
         // ================= drain the leaf queue: one triangle per lane per pass, whatever ray it belongs to
         while (nq > 0) {
-            const uint32_t m = nq < 64u ? nq : 64u;
-            const bool has = lane < m;
-            const uint32_t myref = has ? qref[(qh + lane) % kLeafQ] : 0u;
-            const uint32_t c1 = has ? (myref >> 27) & 3u : 0u;          // triangles in my item - 1
+            // As many items as fill ONE pass of 2 x 64 triangles: taking 64 items whatever they hold left the pass after the first
+            // 128 triangles nearly empty (items hold 2.1 triangles on average on C4: 135 triangles = a full pass + 7 lanes), and a
+            // pass costs a memory round trip whatever it holds: C4 3 560 -> 3 644 Mrays/s.  (Two items per lane, so that a soup's
+            // 1.5-triangle items fill the pass as well -- 50 instead of 30 of 64 lanes -- bought the soup nothing and C4 less: +0.9 %.)
+            const uint32_t m0 = nq < 64u ? nq : 64u;
+            const uint32_t c1 = lane < m0 ? (qref[(qh + lane) % kLeafQ] >> 27) & 3u : 0u;      // triangles in my item - 1
             const unsigned long long b0 = __ballot((c1 & 1u) != 0u), b1 = __ballot((c1 & 2u) != 0u);
             const uint32_t pre = (uint32_t)__popcll(b0 & lt) + 2u * (uint32_t)__popcll(b1 & lt) + lane;
-            const uint32_t total = (uint32_t)__popcll(b0) + 2u * (uint32_t)__popcll(b1) + m;
-            if (has) for (uint32_t k = 0; k <= c1; k++) tril[pre + k] = (uint8_t)((lane << 2) | k);
+            const uint32_t m = (uint32_t)__popcll(__ballot(lane < m0 && pre + c1 + 1u <= 128u));      // a prefix of the items, >= 1
+            const unsigned long long mm = m >= 64u ? ~0ull : (1ull << m) - 1ull;
+            const uint32_t total = (uint32_t)__popcll(b0 & mm) + 2u * (uint32_t)__popcll(b1 & mm) + m;
+            if (lane < m) for (uint32_t k = 0; k <= c1; k++) tril[pre + k] = (uint8_t)((lane << 2) | k);
             wave_sync();
             // two triangles per lane and pass: both fetches are in flight before either test runs
-            for (uint32_t base = 0; base < total; base += 128u) {
-                if (COUNT) { const uint32_t left = total - base; n_drain_it += left > 64u ? 2u : 1u; n_drain_act += left < 128u ? left : 128u; }
+            {
+                const uint32_t base = 0u;                                 // total <= 128: one pass
+                if (COUNT) { n_drain_it += total > 64u ? 2u : 1u; n_drain_act += total; }
                 uint32_t tslot[2] = {0u, 0u}, own[2] = {0u, 0u};
                 bool act[2];
                 for (int u = 0; u < 2; u++) {
