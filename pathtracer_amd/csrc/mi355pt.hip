@@ -250,7 +250,21 @@ __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
-constexpr uint32_t kLeafQ = 256;         // leaf items per wave; a node step needs room for 2 x 64
+// Leaf queue of a wave and when the node loop yields to the drain.  A pass (set-up, node steps, drain, steal) has a fixed cost,
+// so node phases should be long; a drain refreshes the cull distance, so they should not be too long.  Measured with an
+// 8-entry stack window (tools/ab_leafq.sh; 20 M-triangle soup extend ms / C2 Mrays/s / C4 Mrays/s):
+//   256 items, yield above 128: 24.2 / 3 253 / 3 647      512 items, yield above 384: 25.4 / 3 433 / 3 718
+//   512 items, yield above 256: 24.9 / 3 405 / 3 720  <-  (the soup walks 350 nodes per ray: 1-2 % more of them with late drains)
+// Yielding earlier (above 64 / 32 items) loses 7 / 17 % on C4.
+#ifndef PT_LEAFQ
+#define PT_LEAFQ 512
+#endif
+#ifndef PT_LEAF_ROOM
+#define PT_LEAF_ROOM 256
+#endif
+constexpr uint32_t kLeafQ = PT_LEAFQ;     // leaf items per wave; a node step needs room for 2 x 64
+constexpr uint32_t kLeafRoom = PT_LEAF_ROOM;     // the node loop yields to the drain when less room than this is left (>= 128)
+static_assert(kLeafRoom >= 128u && kLeafRoom <= kLeafQ && (kLeafQ & (kLeafQ - 1u)) == 0u, "a node step queues up to 2 x 64 items");
 constexpr uint32_t kNodeLanes = 24;      // the node loop yields when fewer lanes than this can take a step (MI355PT_NODE_LANES)
 constexpr uint32_t kMaxLeaf = ptb::kMaxLeaf;
 constexpr uint32_t kExtendGuard = 1u << 22;
@@ -343,8 +357,9 @@ __global__ void __launch_bounds__(kExtBlockMax) k_trace(DScene S, DPaths P, Para
     auto cull_marg = [&](uint32_t ow) { return (ANY || prm.no_cull == 2u) ? 0.0f : __uint_as_float(PT_MARG(ow)); };
     // A lane's traversal stack is logical entries [sb, sp); the top `stack_entries` (a power of two) of them live in an
     // LDS ring, entries below `lo` in the wave's spill area in global memory.  Depth-first, near-child-first walks keep a
-    // stack of about one entry per level with both children hit: the window is rarely left, and a 16-entry window instead
-    // of a full-depth stack is what lets 16 instead of 12 waves share a CU's LDS.
+    // stack of about one entry per level with both children hit: the window is rarely left, and an 8-entry window instead
+    // of a full-depth stack is what lets 16 waves with 512-item leaf queues share a CU's LDS (8 KB per wave).  8 against 16
+    // entries: C4 and C2 the same, the 20 M-triangle soup 6 % faster (more of the BVH's top fits beside it); 4 entries lose 7 % on C4.
     const uint32_t rmask = prm.stack_entries - 1u;
     uint32_t* spill = (MODE ? P.spill_any : P.spill) + (size_t)wave_id * kStackSize * 64;
 #define PT_STK(i) stk[((i) & rmask) * 64 + lane]
@@ -591,11 +606,11 @@ __global__ void __launch_bounds__(kExtBlockMax) k_trace(DScene S, DPaths P, Para
                 const unsigned long long wm = __ballot(want);
                 const uint32_t nw = (uint32_t)__popcll(wm);
 #ifdef PT_DIAG_BREAKS
-                if (COUNT && (nw == 0 || (!first && nw < th) || kLeafQ - nq < 128u || it >= max_it)) {
-                    if (nw == 0) ck_setup++; else if (!first && nw < th) ck_node++; else if (kLeafQ - nq < 128u) ck_drain++; else ck_rest++;
+                if (COUNT && (nw == 0 || (!first && nw < th) || kLeafQ - nq < kLeafRoom || it >= max_it)) {
+                    if (nw == 0) ck_setup++; else if (!first && nw < th) ck_node++; else if (kLeafQ - nq < kLeafRoom) ck_drain++; else ck_rest++;
                 }
 #endif
-                if (nw == 0 || (!first && nw < th) || kLeafQ - nq < 128u || it >= max_it) break;
+                if (nw == 0 || (!first && nw < th) || kLeafQ - nq < kLeafRoom || it >= max_it) break;
                 first = false; it++;
                 if (COUNT) { n_node_it++; n_node_act += nw; }
                 // window: the top entry in LDS, room for two more above it
@@ -1244,7 +1259,7 @@ static unsigned char* g_scratch_ptr[kMaxDevices] = {nullptr};
 struct mi355pt_scene {
     int device = 0;
     unsigned char* static_scratch = nullptr;     // this device's copy of `scratch`
-    uint32_t static_entries = 16; TraceShape static_shape{1, 0, 0};
+    uint32_t static_entries = 8; TraceShape static_shape{1, 0, 0};
     DScene d{};
     mi355pt_camera camera{};
     std::vector<ptb::MeshTree> trees;
@@ -1694,7 +1709,7 @@ int mi355pt_scene_create(const mi355pt_scene_desc* desc, int32_t device, mi355pt
             g_scratch_ptr[device] = ptr;
         }
         sc->static_scratch = g_scratch_ptr[device];
-        sc->static_entries = std::max(8, sc->max_depth + 3) <= 8 ? 8u : 16u;
+        sc->static_entries = 8u;                     // the renderer's default stack window (mi355pt_render_create)
         sc->static_shape = trace_shape(sc->static_entries, waves_per_workgroup(), top_count);
         if (int rc = allow_large_lds()) return rc;
     }
@@ -1849,11 +1864,11 @@ int mi355pt_render_create(mi355pt_scene* scene, const mi355pt_render_params* par
     }
     hipDeviceProp_t prop; HIP_TRY(hipGetDeviceProperties(&prop, scene->device));
     r->grid = prop.multiProcessorCount * 8;
-    {   // persistent extend kernel: one wave per workgroup, LDS = stack of (tree depth + 4) dwords per lane + the wave's
-        // queues; the grid is the number of waves that are resident at once
-        const int need = std::max(8, scene->max_depth + 3);            // deepest stack a walk can build (host-checked <= kStackSize)
-        int entries = need <= 8 ? 8 : 16;                              // LDS window (power of two); deeper entries spill to P.spill
-        if (const char* e = getenv("MI355PT_STACK_WINDOW")) entries = atoi(e) <= 4 ? 4 : (atoi(e) <= 8 ? 8 : 16);     // test knob: a small window spills all the time
+    {   // persistent extend kernel: LDS per wave = a stack window of 8 dwords per lane + the wave's queues; the grid is the
+        // number of waves that are resident at once.  (The deepest stack a walk can build, tree depth + 3, is host-checked
+        // against kStackSize at scene creation; entries below the window live in the wave's spill area.)
+        int entries = 8;                                               // LDS window (power of two)
+        if (const char* e = getenv("MI355PT_STACK_WINDOW")) entries = atoi(e) <= 4 ? 4 : (atoi(e) <= 8 ? 8 : 16);     // test / A-B knob: a 4-entry window spills all the time
         r->stack_entries = (uint32_t)entries;
         // workgroups of several waves share one LDS copy of the walk records and of the BVH's top records (as many as fit beside
         // 16 waves' own areas); MI355PT_NO_TOP keeps none (A/B knob), MI355PT_WAVES_PER_WG sets the workgroup size

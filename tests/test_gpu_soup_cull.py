@@ -50,7 +50,7 @@ def soup_small():
     pt.close_render()
 
 
-@pytest.mark.parametrize("window", ["16", "4"])
+@pytest.mark.parametrize("window", ["16", "8", "4"])
 def test_soup_c5_small(soup_small, window, monkeypatch):
     s, orc, pt, w, h = soup_small
     monkeypatch.setenv("MI355PT_STACK_WINDOW", window)
