@@ -67,7 +67,7 @@ struct DPaths {
     unsigned long long *stat;   // [0] closest rays [1] shadow rays [2] samples [3,4] extend node visits / tri tests [5,6] visibility ditto [7] guard
                                 // [8..15] counting builds' diagnostics [16] vertices shaded [17] bilinear texture lookups [18] rays bounce 0's pre-pass finished in the current run
 };
-struct Params { uint32_t seed, width, height, max_bounces, rr_start, stack_entries, node_lanes, owner_lanes, gen, use_prep, no_cull, ntop; };
+struct Params { uint32_t seed, width, height, max_bounces, rr_start, stack_entries, node_lanes, owner_lanes, gen, use_prep, no_cull, ntop, setup_min; };
 
 __device__ __forceinline__ F3 xyz(float4 v) { return f3(v.x, v.y, v.z); }
 __device__ __forceinline__ float4 f4(F3 v, float w) { return make_float4(v.x, v.y, v.z, w); }
@@ -421,7 +421,12 @@ __global__ void __launch_bounds__(kExtBlockMax) k_trace(DScene S, DPaths P, Para
         // thousand passes; the guard turns a scheduling bug into an error code (stat[7]) instead of a hung GPU
         if (++guard > kExtendGuard) { if (lane == 0) atomicOr(&P.stat[7], 1ull); break; }
         // ================= setup: new rays for idle lanes, next object / mesh for lanes between meshes
-        {
+        // The phase costs a wave the same for 3 lanes as for 40 (a chain of dependent loads: queue entry -> ray -> records): it is
+        // skipped while fewer than `setup_min` lanes (32; MI355PT_SETUP_MIN, 1 = never skip) wait for it and the node loop has
+        // enough lanes to go on.  C4 +0.9 %, C2 +1.7 %, the 20 M-triangle soup's extend 25.1 -> 23.4 ms; 28 / 32 / 40 the same.
+        const bool skip_setup = prm.setup_min > 1u && (uint32_t)__popcll(__ballot(state == LS_IDLE || state == LS_SETUP)) < prm.setup_min &&
+                                (uint32_t)__popcll(__ballot(sp != sb)) >= prm.node_lanes && nq < kLeafQ - kLeafRoom;
+        if (!skip_setup) {
             Ray wr; wr.p = wr.d = f3(0, 0, 0);
             if (state == LS_SETUP) load_world(slot, wr);
             bool claimed = false;
@@ -1314,7 +1319,7 @@ struct mi355pt_render {
     struct Ev { hipEvent_t a, b; int kind; };
     std::vector<Ev> events; bool ev_open = false;
     double ms[4] = {0, 0, 0, 0}; uint64_t extend_launches = 0;
-    int grid = 2048, extend_grid = 768; TraceShape shape{1, 0, 0}; uint32_t stack_entries = 8, node_lanes = kNodeLanes, owner_lanes = 64;
+    int grid = 2048, extend_grid = 768; TraceShape shape{1, 0, 0}; uint32_t stack_entries = 8, node_lanes = kNodeLanes, owner_lanes = 64, setup_min = 32;
     ~mi355pt_render() {
         for (auto& e : events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
         for (hipEvent_t e : fork) (void)hipEventDestroy(e);
@@ -1883,6 +1888,7 @@ int mi355pt_render_create(mi355pt_scene* scene, const mi355pt_render_params* par
     }
     // test knobs: results must not depend on either (tests/test_gpu_parity.py::test_traversal_schedule_*)
     if (const char* e = getenv("MI355PT_NODE_LANES")) r->node_lanes = (uint32_t)std::min(64, std::max(1, atoi(e)));
+    if (const char* e = getenv("MI355PT_SETUP_MIN")) r->setup_min = (uint32_t)std::min(40, std::max(1, atoi(e)));
     if (const char* e = getenv("MI355PT_OWNER_LANES")) r->owner_lanes = (uint32_t)std::min(64, std::max(1, atoi(e)));
     r->count_work = getenv("MI355PT_COUNT_WORK") != nullptr;
     r->no_cull = getenv("MI355PT_NO_CULL") ? 1u : (getenv("MI355PT_CULL_PLAIN") ? 2u : 0u);
@@ -1973,6 +1979,7 @@ int run_paths(mi355pt_render* r, uint32_t n, uint32_t jitter = 1, uint32_t only_
     DPaths& P = r->P; const mi355pt_render_params& p = r->prm;
     const DScene& S = r->scene->d;
     Params prm{p.seed, p.width, p.height, p.max_bounces, p.rr_start, r->stack_entries, r->node_lanes, r->owner_lanes, ++r->gen, 0u, r->no_cull};
+    prm.setup_min = r->setup_min;
     HIP_TRY(hipMemsetAsync(r->ctr, 0, r->ctr_bytes, r->stream));     // counts, svcounts, work, vwork, lwork
     const int g = grid_for(r, n);
     const int ge = (int)std::max<size_t>(1, std::min<size_t>(((size_t)n + 63) / 64, (size_t)r->extend_grid));     // persistent: resident waves only
@@ -2142,6 +2149,7 @@ int mi355pt_trace_primary(mi355pt_render* r, uint32_t x0, uint32_t y0, uint32_t 
     int32_t *dn = (int32_t*)r->hook, *dm = dn + n, *df = dm + n; float* dt = (float*)(df + n);
     const mi355pt_render_params& p = r->prm;
     Params prm{p.seed, p.width, p.height, p.max_bounces, p.rr_start, r->stack_entries, r->node_lanes, r->owner_lanes};
+    prm.setup_min = r->setup_min;
     hipLaunchKernelGGL(k_primary_init, dim3(grid_for(r, n)), dim3(kBlock), 0, r->stream, r->P, prm, x0, y0, rw, rh);
     const int rc = run_paths(r, (uint32_t)n, 0, 1);
     if (rc == MI355PT_OK) hipLaunchKernelGGL(k_primary_out, dim3(grid_for(r, n)), dim3(kBlock), 0, r->stream, r->scene->d, r->P, (uint32_t)n, dn, dm, df, dt);
@@ -2210,6 +2218,7 @@ int mi355pt_trace_visibility(mi355pt_render* r, const float* origins, const floa
     HIP_TRY(hipMemcpy(r->P.svcounts, &sv, sizeof(sv), hipMemcpyHostToDevice));
     const mi355pt_render_params& p = r->prm;
     Params prm{p.seed, p.width, p.height, p.max_bounces, p.rr_start, r->stack_entries, r->node_lanes, r->owner_lanes, ++r->gen, 0u, r->no_cull};
+    prm.setup_min = r->setup_min;
     const int ge = (int)std::max<size_t>(1, std::min<size_t>((n + 63) / 64, (size_t)r->extend_grid));
     const DScene& S = r->scene->d;
     if (r->scene->model_lights) launch_trace<2>(false, (size_t)ge, r->shape, r->stream, S, r->P, prm, 0u, count);
@@ -2267,6 +2276,7 @@ int mi355pt_trace_rays_static(mi355pt_scene* scene, const float* d_origins, cons
     // the array keeps the last call's contents: the work counter and the guard word must start at zero
     HIP_TRY(hipMemsetAsync(base + kStaticCtrOff, 0, 256, st));
     Params prm{0u, 1u, 1u, 1u, 0u, scene->static_entries, kNodeLanes, 64u, 0u, 0u};
+    prm.setup_min = 32u;                    // the renderer's default (mi355pt_render)
     const int g = (int)std::max<size_t>(1, std::min<size_t>(((size_t)count + kBlock - 1) / kBlock, 2048));
     const int ge = (int)std::max<size_t>(1, std::min<size_t>(((size_t)count + 63) / 64, kStaticWaves));
     hipLaunchKernelGGL(k_static_in, dim3(g), dim3(kBlock), 0, st, d_origins, d_dirs, count, P.ray);

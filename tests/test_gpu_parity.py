@@ -234,12 +234,14 @@ def test_chain_record_ray_through_mesh_origin():
 def test_traversal_schedule_same_results(built, name, monkeypatch):
     """MI355PT_OWNER_LANES=3 lets only 3 lanes of a wave own rays: the other 61 steal subtrees all the time;
     MI355PT_NODE_LANES=64 drains the leaf queue after almost every node step; MI355PT_STACK_WINDOW=4 keeps only
-    four stack entries in LDS.  Hits and radiance must not depend on who walks which subtree, when its triangles
-    are tested, or where a stack entry was kept."""
+    four stack entries in LDS; MI355PT_SETUP_MIN=1 runs the set-up phase in every pass instead of when 32 lanes wait
+    for it.  Hits and radiance must not depend on who walks which subtree, when its triangles are tested, where a stack
+    entry was kept, or when a lane got its next ray."""
     s, orc, pt, w, h = built(name)
     monkeypatch.setenv("MI355PT_OWNER_LANES", "3")
     monkeypatch.setenv("MI355PT_NODE_LANES", "64")
     monkeypatch.setenv("MI355PT_STACK_WINDOW", "4")          # 4-entry LDS stack window: deeper entries go through the spill area
+    monkeypatch.setenv("MI355PT_SETUP_MIN", "1")
     p2 = PathTracer(pt.dscene)
     p2.Init(w, h)
     node, mesh, face, t = p2.trace_primary()
