@@ -363,7 +363,7 @@ __global__ void __launch_bounds__(kExtBlockMax) k_trace(DScene S, DPaths P, Para
     const uint32_t rmask = prm.stack_entries - 1u;
     uint32_t* spill = (MODE ? P.spill_any : P.spill) + (size_t)wave_id * kStackSize * 64;
 #define PT_STK(i) stk[((i) & rmask) * 64 + lane]
-#define PT_SPILL(i) spill[(i) * 64 + lane]
+#define PT_SPILL(i) ((PT_GLOBAL_AS uint32_t*)spill)[(i) * 64 + lane]      // (explicit: `cond ? PT_STK(i) : PT_SPILL(i)` must not become one flat load)
     WorkCounters wc; wc.nodes = 0; wc.tris = 0; wc.top = 0;
     uint32_t state = LS_IDLE, slot = 0, rec = 0, sp = 0, sb = 0, lo = 0, owner = lane;
     F3 o = f3(0, 0, 0), inv = f3(0, 0, 0);
@@ -446,7 +446,7 @@ __global__ void __launch_bounds__(kExtBlockMax) k_trace(DScene S, DPaths P, Para
                     if (state == LS_IDLE) {
                         const uint32_t idx = pool_next + (uint32_t)__popcll(need & lt);
                         if (idx < pool_end) {
-                            slot = q ? q[idx] : idx;
+                            slot = q ? ((const PT_GLOBAL_AS uint32_t*)q)[idx] : idx;      // (q is picked from an array of pointers: say where it points)
                             rec = 0; state = LS_SETUP;
                             if (MODE == 0 && use_prep) {                      // k_prepare has walked this ray up to its first mesh
                                 const float4* A = P.prep + 4 * (size_t)slot;
@@ -475,12 +475,16 @@ __global__ void __launch_bounds__(kExtBlockMax) k_trace(DScene S, DPaths P, Para
                                 const float tmax = (slot & 1u) ? kBig : sh[SHV_O].w;
                                 const DLight& L = S.lights[__float_as_int(sh[SHV_W1].w)];
                                 linst = (uint32_t)L.inst;
-                                const float4* R = (uint32_t)L.rec < ncache ? (const float4*)(recl + L.rec * kRecStride) : S.recs + (size_t)L.rec * kRecStride;
+                                // the light's walk record, from the LDS cache or from memory: two calls, not one call on a selected pointer
+                                // (which would read the record with flat loads)
+                                auto light_ray = [&](auto R) { return rec_ray(S, R, __float_as_uint(R[0].y), linst, wr, 1u); };
+                                const uint32_t lrec = (uint32_t)L.rec;
+                                auto light_ray_at = [&]() { return lrec < ncache ? light_ray((const float4*)(recl + lrec * kRecStride)) : light_ray(S.recs + (size_t)lrec * kRecStride); };
                                 float lz = 0.0f; bool front = false, hit;
                                 if (S.plane_lights_only) {                        // scalar branch: the usual scene
                                     if (slot & 1u) { hit = true; front = true; lz = sh[SHV_W2].w; }      // the MIS ray was tested by k_shade
                                     else {
-                                        const Ray lr = rec_ray(S, R, __float_as_uint(R[0].y), linst, wr, 1u);
+                                        const Ray lr = light_ray_at();
                                         F3 Pp;
                                         hit = plane_hit(lr.p, lr.d, SIDE_BOTH, lz, front, Pp);
                                     }
@@ -490,7 +494,7 @@ __global__ void __launch_bounds__(kExtBlockMax) k_trace(DScene S, DPaths P, Para
                                     hit = mh.inst >= 0; lz = mh.t;
                                     if (hit) { Ray w0; w0.p = xyz(sh[SHV_O]); w0.d = xyz(sh[(slot & 1u) ? SHV_W2 : SHV_W1]); front = model_hit_front(S, L, mh, w0); }
                                 } else {
-                                    const Ray lr = rec_ray(S, R, __float_as_uint(R[0].y), linst, wr, 1u);
+                                    const Ray lr = light_ray_at();
                                     F3 Pp;
                                     hit = L.kind == MI355PT_OBJ_PLANE ? plane_hit(lr.p, lr.d, SIDE_BOTH, lz, front, Pp) : sphere_hit(lr.p, lr.d, SIDE_BOTH, lz, front, Pp);
                                 }
@@ -643,6 +647,9 @@ __global__ void __launch_bounds__(kExtBlockMax) k_trace(DScene S, DPaths P, Para
                     const uint32_t te = e - S.top_base;               // < ntop: the record is in LDS
                     const float4* np = S.bvh_nodes + 4 * (size_t)e;
                     float4 w0, w1, w2, w3;
+                    // (The compiler merges the two branches into ONE set of flat loads through a selected pointer.  That is the better code:
+                    //  with explicit address spaces a wave whose lanes are split between the LDS copy and memory issues four ds_reads AND
+                    //  four global loads per step -- measured 0.8 % slower on C4.)
                     if (te < prm.ntop) { const float4* tp = topl + 4 * te; w0 = tp[0]; w1 = tp[1]; w2 = tp[2]; w3 = tp[3]; if (COUNT) wc.top++; }
                     else { w0 = np[0]; w1 = np[1]; w2 = np[2]; w3 = np[3]; }
                     if (COUNT) wc.nodes++;
@@ -824,13 +831,17 @@ k_shade(DScene S, DCamera cam, DPaths P, Params prm, uint32_t bounce, uint32_t n
     // The way from a hit record to its surface is a chain of dependent per-lane loads from small tables: instance -> node chain
     // (level by level, into the object and back) -> material -> light.  They are cached, but a vector load that hits L1 still
     // takes several hundred cycles and this kernel has two waves per SIMD to hide them: a third of the wave time on the
-    // all-analytic C3 went there.  Scenes whose tables fit (shade_table_bytes) and whose materials have no maps get a copy
-    // in LDS per workgroup: C4 3 470 -> 3 555 Mrays/s, C3 9 830 -> 10 360, C1 unchanged; the textured C2 lost 4 % with it
-    // (with or without the materials in the copy), hence the second condition.
-    // (TABLES is a template parameter: pointers that MAY point into LDS turn every access through them into a flat load,
-    // which cost the textured C2 15 % even with the copy switched off at run time.)
+    // all-analytic C3 went there.  Scenes whose tables fit (shade_table_bytes) get a copy in LDS per workgroup, read with
+    // ds_read instructions: C4 shade 55 -> 40 ms per step, C3 110 -> 71 ms, C2 39.4 -> 35.9 ms, C1 5.9 -> 4.4 ms.
+    // Two conditions make the compiler see LDS pointers instead of generic ones (checked in the code object: the TABLES
+    // instances have as many flat loads as the others and ~95 more ds instructions):
+    //  * TABLES is a template parameter -- pointers that MAY point into LDS turn every access through them into a flat load;
+    //  * DScene holds no dynamically indexed array -- changing four pointers of the by-value kernel argument makes a private
+    //    copy of it, which is split into registers only if every access to it has a constant offset; with the filter taps
+    //    inside, the copy lived in scratch and EVERY pointer of the scene came back generic (230 flat loads, the tables
+    //    themselves read through the flat path).  The taps are in constant memory now (g_filter_taps).
     extern __shared__ float4 tables[];
-    if (TABLES && lds_tables) {
+    if (TABLES) {                                                // (launched only with lds_tables != 0: a run-time choice would make the pointers generic)
         const uint32_t ni = (uint32_t)S.num_insts * (uint32_t)sizeof(DInst) / 16u, nn = ((uint32_t)S.num_nodes * (uint32_t)sizeof(DNodeXf) + 15u) / 16u;
         const uint32_t nm = ((uint32_t)S.num_materials * (uint32_t)sizeof(mi355pt_material) + 15u) / 16u, nl = (uint32_t)S.num_lights * (uint32_t)sizeof(DLight) / 16u;
         for (uint32_t k = threadIdx.x; k < ni; k += 64u) tables[k] = ((const float4*)S.insts)[k];
@@ -1273,7 +1284,6 @@ struct mi355pt_scene {
     DevBuf<mi355pt_material> materials; DevBuf<mi355pt_texmap> texmaps; DevBuf<DTexture> textures; DevBuf<DAtlas> atlases; DevBuf<int> mtl_atlas; DevBuf<DLight> lights; DevBuf<float> light_data;
     bool model_lights = false;        // some light sits on a Model: its own-object test is a BVH traversal (k_trace<2>)
     uint32_t mtl_kinds = 0;           // bit 0: some material is Disney, bit 1: some is Cook-Torrance ("standard")
-    bool any_maps = false;            // some material has a texture map (k_shade then keeps its tables in global memory)
     bool no_shade_tables = false;     // MI355PT_NO_SHADE_TABLES at scene creation: the same for every scene (the A/B and test switch)
     // Renderers keep a pointer to their scene: scene_destroy while some are alive only marks the scene, and the last
     // render_destroy frees it (a reference maintainer's Restart() tears things down in whatever order it likes).
@@ -1618,7 +1628,6 @@ int mi355pt_scene_create(const mi355pt_scene_desc* desc, int32_t device, mi355pt
     for (auto& m : materials) {
         if (m.kind != MI355PT_MTL_DISNEY && m.kind != MI355PT_MTL_STANDARD) return fail(MI355PT_ERR_UNSUPPORTED, "unknown material kind");
         sc->mtl_kinds |= m.kind == MI355PT_MTL_DISNEY ? 1u : 2u;
-        if (m.albedo_map >= 0 || m.roughness_map >= 0 || m.metalness_map >= 0 || m.normal_map >= 0) sc->any_maps = true;
     }
     auto bad_map = [&](int m) { return m >= (int)desc->num_texmaps; };
     for (auto& m : materials) if (bad_map(m.albedo_map) || bad_map(m.roughness_map) || bad_map(m.metalness_map) || bad_map(m.normal_map)) return fail(MI355PT_ERR_INVALID, "bad texmap index");
@@ -1696,18 +1705,25 @@ int mi355pt_scene_create(const mi355pt_scene_desc* desc, int32_t device, mi355pt
     d.recs = sc->recs.p; d.num_recs = (int)(recs.size() / kRecStride);
     d.top_base = top_base; d.top_count = top_count;
     memcpy(d.env_color, desc->env_color, sizeof(d.env_color)); d.env_map = desc->env_map;
-    for (int i = 0; i < 32; i++) {      // Texture::Sample tap offsets (scene.h:169-175), host libm like the reference
+    // Texture::Sample tap offsets (scene.h:169-175), host libm like the reference: the same 64 floats for every scene.  They live in
+    // constant memory of the device (g_filter_taps, pt_shade.h), not in an array inside DScene: k_shade's TABLES instances change
+    // four pointers of their DScene, and a struct with a dynamically indexed array in it lives in scratch memory from then on,
+    // every pointer in it read back as a generic one -- flat loads throughout, the tables read through the flat path instead of
+    // ds_read (C4 shade 48.5 -> 40.0 ms, C3 97 -> 71 ms once the array was gone).
+    std::vector<float> taps(64);
+    for (int i = 0; i < 32; i++) {
         auto halton = [](int index, int base) { float r = 0; float f = 1.0f / (float)base; for (int k = index; k > 0; k /= base) { r += f * (k % base); f /= (float)base; } return r; };
         float x = halton(i, 2), y = halton(i, 3);
         const float rr = sqrtf(x) * 0.5f;
         x = rr * sinf(y * (float)M_PI * 2);
         y = rr * cosf(y * (float)M_PI * 2);
-        d.filter_taps[2 * i] = x; d.filter_taps[2 * i + 1] = y;
+        taps[2 * i] = x; taps[2 * i + 1] = y;
     }
     {   // set-up of mi355pt_trace_rays_static for this device: the address of this GPU's copy of the static array
         if (device >= kMaxDevices) return fail(MI355PT_ERR_TOO_LARGE, "device ordinal beyond the static scratch table");
         std::lock_guard<std::mutex> g(g_scratch_mu);
         if (!g_scratch_ptr[device]) {
+            HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_filter_taps), taps.data(), 64 * sizeof(float)));      // once per device
             unsigned char* ptr = nullptr;
             HIP_TRY(hipGetSymbolAddress((void**)&ptr, HIP_SYMBOL(scratch)));
             if (!ptr) return fail(MI355PT_ERR_HIP, "hipGetSymbolAddress(scratch) returned a null address");
@@ -2021,9 +2037,12 @@ int run_paths(mi355pt_render* r, uint32_t n, uint32_t jitter = 1, uint32_t only_
         const uint32_t kinds = r->scene->mtl_kinds ? r->scene->mtl_kinds : 1u;
         // (... and per "the scene has material atlases": the instances without that code keep their registers)
         const uint32_t miss2 = (kinds & 1u) ? 0u : 1u;
-        const uint32_t tb = shade_table_bytes(S, r->scene->any_maps || r->scene->no_shade_tables);
+        const uint32_t tb = shade_table_bytes(S, r->scene->no_shade_tables);
         auto shade = [&](auto kern, uint32_t miss) { hipLaunchKernelGGL(kern, dim3(gs), dim3(kShadeBlock), tb, r->stream, S, r->cam, P, prm, b, n, miss, tb); };
-        if (S.mtl_atlas) {
+        if (S.mtl_atlas && tb) {
+            if (kinds & 1u) shade(k_shade<MI355PT_MTL_DISNEY, true, true>, 1u);
+            if (kinds & 2u) shade(k_shade<MI355PT_MTL_STANDARD, true, true>, miss2);
+        } else if (S.mtl_atlas) {
             if (kinds & 1u) shade(k_shade<MI355PT_MTL_DISNEY, true, false>, 1u);
             if (kinds & 2u) shade(k_shade<MI355PT_MTL_STANDARD, true, false>, miss2);
         } else if (tb) {

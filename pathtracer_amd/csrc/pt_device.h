@@ -11,6 +11,12 @@
 #include "pt_scene.h"
 
 #define PT_DEV __device__ __forceinline__
+// Explicit address spaces for the loads whose pointer the compiler cannot trace to its origin (a pointer read from a table in
+// memory, or one of two pointers chosen at run time): without them such a load is a flat load.
+#define PT_GLOBAL_AS __attribute__((address_space(1)))
+#define PT_LDS_AS __attribute__((address_space(3)))
+typedef unsigned int pt_u2v __attribute__((ext_vector_type(2)));
+typedef float pt_f4v __attribute__((ext_vector_type(4)));
 
 namespace ptd {
 

@@ -75,7 +75,6 @@ struct DScene {
     int             plane_lights_only;   // every light sits on a Plane: the kernels take the short analytic path (uniform branch)
     const float4*   recs;       int num_recs;
     float env_color[3];         int env_map;
-    float filter_taps[64];           // (x, y) of the 32 elliptic filter taps, scene.h:169-181
 };
 
 }  // namespace ptd

@@ -172,11 +172,13 @@ __host__ __device__ __forceinline__ float u8_unorm(unsigned v) {
     const float e = fmaf(-255.0f, q0, x);
     return fmaf(e, r, q0);
 }
+// Texel pointers come out of tables in memory (DTexture::data, DAtlas::data), so the compiler cannot know their address space
+// and would fetch every texel with a flat load; they are global memory, and these loaders say so (PT_GLOBAL_AS, pt_device.h).
 PT_DEV F3 texel(const DTexture& t, int y, int x) {
     const size_t i = (size_t)y * t.width + x;
-    if (t.kind == MI355PT_TEX_RGB32F) { const float4 v = ((const float4*)t.data)[i]; return f3(v.x, v.y, v.z); }
-    const uchar4 v = ((const uchar4*)t.data)[i];
-    return f3(u8_unorm(v.x), u8_unorm(v.y), u8_unorm(v.z));
+    if (t.kind == MI355PT_TEX_RGB32F) { const pt_f4v v = ((const PT_GLOBAL_AS pt_f4v*)t.data)[i]; return f3(v.x, v.y, v.z); }
+    const uint32_t v = ((const PT_GLOBAL_AS uint32_t*)t.data)[i];         // uchar4: r, g, b, -
+    return f3(u8_unorm(v & 255u), u8_unorm((v >> 8) & 255u), u8_unorm((v >> 16) & 255u));
 }
 PT_DEV F3 tex_point(const DTexture& t, F3 uvw) {
     if (t.kind == MI355PT_TEX_CHECKER) {
@@ -199,13 +201,15 @@ PT_DEV F3 tex_point(const DTexture& t, F3 uvw) {
     return texel(t, iy, ix) * ((1 - fx) * (1 - fy)) + texel(t, iy, ixp) * (fx * (1 - fy)) +
            texel(t, iyp, ix) * ((1 - fx) * fy) + texel(t, iyp, ixp) * (fx * fy);
 }
+// (x, y) of the 32 elliptic filter taps of scene.h:169-181, the same for every scene; set once per device by mi355pt_scene_create
+__constant__ float g_filter_taps[64];
 PT_DEV F3 tex_filtered(const DScene& S, const DTexture& t, F3 uvw, F3 d0, F3 d1) {
     F3 c = tex_point(t, uvw);
     if (len2(d0) + len2(d1) == 0) return c;
     for (int i = 1; i < 32; i++) {
         // elliptic tap offsets r*sin, r*cos of scene.h:170-175 are pixel-independent constants:
         // tabulated on the host with libm (mi355pt.hip, init_filter_taps)
-        const float x = S.filter_taps[2 * i], y = S.filter_taps[2 * i + 1];
+        const float x = g_filter_taps[2 * i], y = g_filter_taps[2 * i + 1];
         c = c + tex_point(t, uvw + x * d0 + y * d1);
     }
     return c / 32.0f;
@@ -234,8 +238,9 @@ PT_DEV AtlasTaps atlas_point(const DAtlas& t, F3 uvw) {
     if (iy < 0) iy -= (iy / height - 1) * height;
     if (iy >= height) iy -= (iy / height) * height;
     int iyp = iy + 1; if (iyp >= height) iyp -= height;
-    const uint2 t00 = t.data[(size_t)iy * width + ix], t01 = t.data[(size_t)iy * width + ixp];
-    const uint2 t10 = t.data[(size_t)iyp * width + ix], t11 = t.data[(size_t)iyp * width + ixp];
+    const PT_GLOBAL_AS pt_u2v* td = (const PT_GLOBAL_AS pt_u2v*)t.data;
+    const pt_u2v t00 = td[(size_t)iy * width + ix], t01 = td[(size_t)iy * width + ixp];
+    const pt_u2v t10 = td[(size_t)iyp * width + ix], t11 = td[(size_t)iyp * width + ixp];
     const float w00 = (1 - fx) * (1 - fy), w01 = fx * (1 - fy), w10 = (1 - fx) * fy, w11 = fx * fy;
 #define PT_AT(word, sh) (u8_unorm((t00.word >> sh) & 255u) * w00 + u8_unorm((t01.word >> sh) & 255u) * w01 + \
                          u8_unorm((t10.word >> sh) & 255u) * w10 + u8_unorm((t11.word >> sh) & 255u) * w11)
@@ -254,7 +259,7 @@ PT_DEV AtlasTaps atlas_sample(const DScene& S, const DAtlas& t, const mi355pt_te
     AtlasTaps c = atlas_point(t, u);
     if (len2(e0) + len2(e1) == 0) return c;
     for (int i = 1; i < 32; i++) {
-        const float x = S.filter_taps[2 * i], y = S.filter_taps[2 * i + 1];
+        const float x = g_filter_taps[2 * i], y = g_filter_taps[2 * i + 1];
         const AtlasTaps p = atlas_point(t, u + x * e0 + y * e1);
         c.alb = c.alb + p.alb; c.nrm = c.nrm + p.nrm; c.rough = c.rough + p.rough; c.metal = c.metal + p.metal;
     }
