@@ -34,13 +34,15 @@ using namespace ptd;
 // over the pool (compacted queues), so one ray / hit / shadow record must be one or two aligned 16-byte accesses,
 // not six 4-byte ones in six cache lines.
 enum { SHV_O = 0,      // origin of both visibility rays (hit point + N * bias), w = distance to the light sample
-       SHV_W1,         // direction to the light sample, w = light index (int bits)
-       SHV_W2,         // direction of the MIS BRDF sample, w = light index again (each visibility item reads O and one W)
+       SHV_W1,         // direction to the light sample, w = light index | flags << 28 (int bits; flags bit 0: light sample queued, bit 1: BRDF sample queued)
+       SHV_W2,         // direction of the MIS BRDF sample, w = its distance to the light (scenes with Plane lights only)
        SHV_C1,         // contribution of the light sample if visible, w = pdf of the BRDF sample
        SHV_A2,         // NdotL * f * Le of the BRDF sample, w = 1 / numLights
-       SHV_HP,         // the shaded point, w = flags (bit 0: light sample queued, bit 1: BRDF sample queued)
-       SHV_TB,         // throughput at this vertex
-       kShVec };
+       SHV_TB,         // throughput at this vertex, w = LightComponent::Pdf of the BRDF sample (scenes with Plane lights only)
+       SHV_HP,         // the shaded point -- only in scenes with a light that is not a Plane (k_connect intersects the light there)
+       kShVec };       // the record's stride is DPaths::shv: 6 pieces (96 B) when every light is a Plane, 7 otherwise -- the denser
+                       // record is worth 3-4 % on the all-analytic C3 (and a 128-B aligned one cost 5.5 %)
+constexpr uint32_t kShLightMask = 0x0FFFFFFFu;
 
 struct DPaths {
     uint32_t  cap;
@@ -48,7 +50,8 @@ struct DPaths {
     float4   *ray;        // 2 x cap: (origin, -), (direction, -) of the ray to trace next
     float4   *T, *C;      // throughput, accumulated radiance
     uint4    *hit;        // closest-hit record: (t bits, instance, mesh, triangle slot)
-    float4   *sh;         // kShVec x cap, record-major: NEE / MIS work of the current bounce
+    float4   *sh;         // shv x cap, record-major: NEE / MIS work of the current bounce
+    uint32_t  shv;        // pieces per shadow record (6 or 7, see SHV_HP)
     uint32_t *queue[2];   // path-slot indices, ping-pong
     uint32_t *squeue;     // slots with shadow work this bounce
     uint32_t *counts;     // [b] = #paths entering bounce b (b >= 1)
@@ -381,7 +384,7 @@ __global__ void __launch_bounds__(kExtBlockMax) k_trace(DScene S, DPaths P, Para
         if (MODE == 0) {
             wr.p = xyz(P.ray[2 * (size_t)it]); wr.d = xyz(P.ray[2 * (size_t)it + 1]);
         } else {
-            const float4* sh = P.sh + (size_t)(it >> 1) * kShVec;
+            const float4* sh = P.sh + (size_t)(it >> 1) * P.shv;
             wr.p = xyz(sh[SHV_O]); wr.d = xyz(sh[(it & 1u) ? SHV_W2 : SHV_W1]);
         }
         if (S.num_recs > 0) wr = rec_ray(S, recl, 1u, 0u, wr);   // record 0 is cached in LDS; its level 0 is the root node
@@ -467,15 +470,15 @@ __global__ void __launch_bounds__(kExtBlockMax) k_trace(DScene S, DPaths P, Para
                             if (!ANY) { best_t = kBig; best_inst = -1; best_mesh = -1; best_slot = 0; PT_MARG(lane) = 0u; }
                             }
                             if (OWN) {
-                                const DLight& L = S.lights[__float_as_int(P.sh[(size_t)(slot >> 1) * kShVec + SHV_W1].w)];
+                                const DLight& L = S.lights[__float_as_uint(P.sh[(size_t)(slot >> 1) * P.shv + SHV_W1].w) & kShLightMask];
                                 if (L.kind != MI355PT_OBJ_MODEL) state = LS_IDLE;       // nothing to do for this item
                                 else { rec = (uint32_t)L.rec; rec_end = (uint32_t)L.rec_end; }
                             }
                             if (ANY) {
                                 // (1) the light's own object, both sides: a miss or its back side blocks (raytracer.cpp:67-97,138-145)
-                                const float4* sh = P.sh + (size_t)(slot >> 1) * kShVec;
+                                const float4* sh = P.sh + (size_t)(slot >> 1) * P.shv;
                                 const float tmax = (slot & 1u) ? kBig : sh[SHV_O].w;
-                                const DLight& L = S.lights[__float_as_int(sh[SHV_W1].w)];
+                                const DLight& L = S.lights[__float_as_uint(sh[SHV_W1].w) & kShLightMask];
                                 linst = (uint32_t)L.inst;
                                 // the light's walk record, from the LDS cache or from memory: two calls, not one call on a selected pointer
                                 // (which would read the record with flat loads)
@@ -1015,9 +1018,10 @@ k_shade(DScene S, DCamera cam, DPaths P, Params prm, uint32_t bounce, uint32_t n
                         }
                         if (flags) {
                             const F3 so = h.p + h.N * kBias;
-                            float4* sh = P.sh + (size_t)slot * kShVec;
-                            sh[SHV_O] = f4(so, dist); sh[SHV_W1] = f4(wi1, __int_as_float(li)); sh[SHV_W2] = f4(wi2, S.plane_lights_only ? mis_lz : __int_as_float(li));
-                            sh[SHV_C1] = f4(c1, pdf2); sh[SHV_A2] = f4(A2, selectPdf); sh[SHV_HP] = f4(h.p, __uint_as_float(flags)); sh[SHV_TB] = f4(T, mis_pdf);
+                            float4* sh = P.sh + (size_t)slot * P.shv;
+                            sh[SHV_O] = f4(so, dist); sh[SHV_W1] = f4(wi1, __uint_as_float((uint32_t)li | (flags << 28))); sh[SHV_W2] = f4(wi2, mis_lz);
+                            sh[SHV_C1] = f4(c1, pdf2); sh[SHV_A2] = f4(A2, selectPdf); sh[SHV_TB] = f4(T, mis_pdf);
+                            if (!S.plane_lights_only) sh[SHV_HP] = f4(h.p, 0.0f);
                             shadow = true; vflags = flags;
                         }
                     }
@@ -1074,9 +1078,9 @@ __global__ void __launch_bounds__(kBlock) k_connect(DScene S, DPaths P, uint32_t
     unsigned long long rays = 0;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const uint32_t slot = P.squeue[i];
-        const float4* sh = P.sh + (size_t)slot * kShVec;
-        const float4 w2 = sh[SHV_W2], c1 = sh[SHV_C1], a2 = sh[SHV_A2], hpf = sh[SHV_HP];
-        const uint32_t flags = __float_as_uint(hpf.w);
+        const float4* sh = P.sh + (size_t)slot * P.shv;
+        const float4 w1 = sh[SHV_W1], c1 = sh[SHV_C1], a2 = sh[SHV_A2];
+        const uint32_t flags = __float_as_uint(w1.w) >> 28;
         F3 direct = f3(0, 0, 0);
         if (flags & 1u) {
             rays++;
@@ -1090,8 +1094,8 @@ __global__ void __launch_bounds__(kBlock) k_connect(DScene S, DPaths P, uint32_t
                 float lightPdf;
                 if (S.plane_lights_only) lightPdf = sh[SHV_TB].w;
                 else {
-                const DLight& L = S.lights[__float_as_int(sh[SHV_W1].w)];
-                Ray r; r.p = xyz(sh[SHV_O]); r.d = xyz(w2);
+                const DLight& L = S.lights[__float_as_uint(w1.w) & kShLightMask];
+                Ray r; r.p = xyz(sh[SHV_O]); r.d = xyz(sh[SHV_W2]);
                 F3 lp, ln;
                 HitRec mh; mh.t = 0.0f; mh.inst = -1; mh.mesh = -1; mh.slot = 0;
                 if (L.kind == MI355PT_OBJ_MODEL) {
@@ -1099,7 +1103,7 @@ __global__ void __launch_bounds__(kBlock) k_connect(DScene S, DPaths P, uint32_t
                     mh.t = __uint_as_float(v.x); mh.inst = (int)v.y; mh.mesh = (int)v.z; mh.slot = v.w;
                 }
                 light_hit_point(S, r, L, mh, lp, ln);
-                const F3 hp = xyz(hpf);
+                const F3 hp = xyz(sh[SHV_HP]);
                 lightPdf = light_pdf(L, hp, lp, ln, len(lp - hp));
                 }
                 if (!(lightPdf <= 0.0f)) {
@@ -1808,7 +1812,7 @@ int mi355pt_render_create(mi355pt_scene* scene, const mi355pt_render_params* par
     if (const char* e = getenv("MI355PT_OVERLAP_FROM")) r->overlap_from = (uint32_t)std::max(0, atoi(e));
     if (const char* e = getenv("MI355PT_SLOT_GROUP")) r->slot_group = (uint32_t)std::max(0, atoi(e));
     const size_t npix = (size_t)params->width * params->height;
-    // Path slots of one chunk.  Sixteen samples of a 4K frame fit (294 B per slot, 39.5 GB of the 288): a step of several samples runs them as ONE batch, and the fixed
+    // Path slots of one chunk.  Sixteen samples of a 4K frame fit (278 or 294 B per slot, 37.3 or 39.5 GB of the 288): a step of several samples runs them as ONE batch, and the fixed
     // cost of a batch -- above all the ~20 late bounces that a few thousand Russian-roulette survivors drag out at one ray's
     // latency each (3.4 of 18 ms for a single 4K sample of C4, profiles/r02b_timeline.txt) -- is paid once per batch.
     // C4, samples per batch 8 / 16 / 24 / 32: 3 320 / 3 413 / 3 445 / 3 468 Mrays/s -- 16 is where the curve flattens.
@@ -1819,7 +1823,7 @@ int mi355pt_render_create(mi355pt_scene* scene, const mi355pt_render_params* par
     auto dalloc = [&](void** p, size_t bytes) -> hipError_t { hipError_t e = hipMalloc(p, bytes); if (e == hipSuccess) r->allocs.push_back(*p); return e; };
     DPaths& P = r->P; P.cap = (uint32_t)cap;
     HIP_TRY(dalloc((void**)&P.id, cap * 16)); HIP_TRY(dalloc((void**)&P.ray, cap * 32)); HIP_TRY(dalloc((void**)&P.T, cap * 16)); HIP_TRY(dalloc((void**)&P.C, cap * 16));
-    HIP_TRY(dalloc((void**)&P.hit, cap * 16)); HIP_TRY(dalloc((void**)&P.sh, cap * 16 * kShVec));
+    HIP_TRY(dalloc((void**)&P.hit, cap * 16)); P.shv = scene->d.plane_lights_only ? (uint32_t)SHV_HP : (uint32_t)kShVec; HIP_TRY(dalloc((void**)&P.sh, cap * 16 * P.shv));
     HIP_TRY(dalloc((void**)&P.queue[0], cap * 4)); HIP_TRY(dalloc((void**)&P.queue[1], cap * 4)); HIP_TRY(dalloc((void**)&P.squeue, cap * 4));
     const size_t nb = params->max_bounces + 2;
     {   // the per-bounce counters live in one block: one memset per run instead of five
@@ -2223,12 +2227,13 @@ int mi355pt_trace_visibility(mi355pt_render* r, const float* origins, const floa
     HIP_TRY(hipSetDevice(r->device));
     const size_t n = count;
     // one visibility item per ray, shaped like the ones k_shade queues for a light sample (item = slot * 2 + 0)
-    std::vector<float4> sh(kShVec * n, make_float4(0.0f, 0.0f, 0.0f, 0.0f));
+    const size_t shv = r->P.shv;
+    std::vector<float4> sh(shv * n, make_float4(0.0f, 0.0f, 0.0f, 0.0f));
     std::vector<uint32_t> vq(n);
     float lf; memcpy(&lf, &light, 4);
     for (size_t i = 0; i < n; i++) {
-        sh[kShVec * i + SHV_O] = make_float4(origins[3 * i], origins[3 * i + 1], origins[3 * i + 2], tmax[i]);
-        sh[kShVec * i + SHV_W1] = make_float4(dirs[3 * i], dirs[3 * i + 1], dirs[3 * i + 2], lf);
+        sh[shv * i + SHV_O] = make_float4(origins[3 * i], origins[3 * i + 1], origins[3 * i + 2], tmax[i]);
+        sh[shv * i + SHV_W1] = make_float4(dirs[3 * i], dirs[3 * i + 1], dirs[3 * i + 2], lf);
         vq[i] = (uint32_t)(2 * i);
     }
     HIP_TRY(hipStreamSynchronize(r->stream));
