@@ -1121,6 +1121,94 @@ __global__ void __launch_bounds__(kBlock) k_connect(DScene S, DPaths P, uint32_t
     wave_add64(rays, &P.stat[1]);
 }
 
+// ---------------------------------------------------------------------- visibility + connect for scenes without Models
+// A scene of Planes and Spheres only (C1, C3: the Cornell boxes) has no BVH to traverse: a visibility item is a sweep over a
+// handful of walk records.  k_trace<ANY> runs that sweep in its set-up phase -- the persistent-wave machinery around it (leaf
+// queues, stacks, stealing) has nothing to do -- and k_connect then reads the record a second time.  This kernel does both in
+// one streaming pass over the vertices of the bounce (one lane per vertex, both rays): LightVisTest (raytracer.cpp:67-152)
+// with the same record walk and the same arithmetic as k_trace<ANY>'s set-up, then k_connect's combination, the visibility
+// results never leaving registers.  Same results bit for bit (MI355PT_NO_ANALYTIC_VIS switches back; tests/test_gpu_parity.py).
+__global__ void __launch_bounds__(kBlock) k_vis_connect(DScene S, DPaths P, uint32_t bounce) {
+    const uint32_t n = (uint32_t)(P.svcounts[bounce] & 0xFFFFFFFFull);
+    unsigned long long rays = 0;
+    // the first walk records in LDS, as in k_trace (every lane walks the same records: from memory the six planes of C3 cost
+    // more than the two kernels this one replaces)
+    __shared__ float4 recl[kRecCache * kRecStride];
+    const uint32_t ncache = (uint32_t)S.num_recs < kRecCache ? (uint32_t)S.num_recs : kRecCache;
+    for (uint32_t k = threadIdx.x; k < ncache * kRecStride; k += blockDim.x) recl[k] = S.recs[k];
+    __syncthreads();
+    // one call per address space (a selected pointer would make every record read a flat load)
+    auto to_obj = [&](auto R, uint32_t inst, const Ray& wr) { return rec_ray(S, R, __float_as_uint(R[0].y), inst, wr, 1u); };
+    auto to_obj_at = [&](uint32_t rec, uint32_t inst, const Ray& wr) {
+        return rec < ncache ? to_obj((const float4*)(recl + rec * kRecStride), inst, wr) : to_obj(S.recs + (size_t)rec * kRecStride, inst, wr);
+    };
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const uint32_t slot = P.squeue[i];
+        const float4* sh = P.sh + (size_t)slot * P.shv;
+        const float4 o4 = sh[SHV_O], w1 = sh[SHV_W1], w2 = sh[SHV_W2], c1 = sh[SHV_C1], a2 = sh[SHV_A2];
+        const uint32_t flags = __float_as_uint(w1.w) >> 28;
+        const DLight& L = S.lights[__float_as_uint(w1.w) & kShLightMask];
+        const uint32_t linst = (uint32_t)L.inst;
+        bool blocked[2] = {false, false};
+        for (uint32_t which = 0; which < 2u; which++) {
+            if (!(flags & (1u << which))) continue;
+            rays++;
+            Ray wr; wr.p = xyz(o4); wr.d = which ? xyz(w2) : xyz(w1);
+            if (S.num_recs > 0) wr = rec_ray(S, (const float4*)recl, 1u, 0u, wr);
+            // (1) the light's own object, both sides: a miss or its back side blocks (raytracer.cpp:67-97, 138-145)
+            const float tmax = which ? kBig : o4.w;
+            float lz = 0.0f; bool front = false, hit;
+            if (S.plane_lights_only && which) { hit = true; front = true; lz = w2.w; }          // the MIS ray was tested by k_shade
+            else {
+                const Ray lr = to_obj_at((uint32_t)L.rec, linst, wr);
+                F3 Pp;
+                hit = L.kind == MI355PT_OBJ_PLANE ? plane_hit(lr.p, lr.d, SIDE_BOTH, lz, front, Pp) : sphere_hit(lr.p, lr.d, SIDE_BOTH, lz, front, Pp);
+            }
+            if (!hit || !front) { blocked[which] = true; continue; }
+            const float bound = tmax < lz ? tmax : lz;                    // (2) an occluder blocks iff z < tmax && z < lightZ
+            for (uint32_t rec = 0; rec < (uint32_t)S.num_recs;) {
+                const uint32_t cur = rec;
+                float4 h0, h1;
+                if (cur < ncache) { h0 = recl[cur * kRecStride]; h1 = recl[cur * kRecStride + 1]; }
+                else { const float4* R = S.recs + (size_t)cur * kRecStride; h0 = R[0]; h1 = R[1]; }
+                const uint32_t kind = __float_as_uint(h0.x), nexti = __float_as_uint(h0.z);
+                const uint32_t rii = __float_as_uint(h1.x);
+                rec = nexti;
+                if (rii == linst) continue;                               // the light's own object is not an occluder
+                const Ray lr = to_obj_at(cur, rii, wr);
+                float t; bool fr; F3 Pp;
+                const bool oh = kind == MI355PT_OBJ_PLANE ? plane_hit(lr.p, lr.d, SIDE_FRONT, t, fr, Pp) : sphere_hit(lr.p, lr.d, SIDE_FRONT, t, fr, Pp);
+                if (oh && t < bound) { blocked[which] = true; break; }
+            }
+        }
+        // ---- k_connect's combination
+        F3 direct = f3(0, 0, 0);
+        if ((flags & 1u) && !blocked[0]) direct = direct + xyz(c1);
+        if ((flags & 2u) && !blocked[1]) {
+            float lightPdf;
+            if (S.plane_lights_only) lightPdf = sh[SHV_TB].w;
+            else {
+                Ray r; r.p = xyz(o4); r.d = xyz(w2);
+                F3 lp, ln;
+                HitRec mh; mh.t = 0.0f; mh.inst = -1; mh.mesh = -1; mh.slot = 0;
+                light_hit_point(S, r, L, mh, lp, ln);
+                const F3 hp = xyz(sh[SHV_HP]);
+                lightPdf = light_pdf(L, hp, lp, ln, len(lp - hp));
+            }
+            if (!(lightPdf <= 0.0f)) {
+                const float pb = c1.w;
+                const float w = (pb * pb) / (pb * pb + lightPdf * lightPdf);
+                direct = direct + xyz(a2) * w / pb;
+            }
+        }
+        const F3 Tb = xyz(sh[SHV_TB]);
+        F3 C = xyz(P.C[slot]);
+        C = C + Tb * (direct / a2.w);
+        P.C[slot] = f4(C, 0.0f);
+    }
+    wave_add64(rays, &P.stat[1]);
+}
+
 // ---------------------------------------------------------------------- resolve
 // NaN/Inf -> black, ACES, gamma (render.h:218-243), running mean and RGB8 truncation
 // (pathtracer.cpp:76-101) for the `ns` samples of each pixel of the chunk, in sample order.
@@ -1296,6 +1384,7 @@ struct mi355pt_scene {
     std::mutex life; int renderers = 0; bool doomed = false;
     std::vector<void*> tex_data;
     uint64_t num_tris = 0, num_bvh_nodes = 0; int max_depth = 0;
+    bool analytic_only = false;       // no Model in the scene: Planes and Spheres only (k_vis_connect)
     ~mi355pt_scene() {
         nodes.release(); insts.release(); models.release(); meshes.release(); bvh_nodes.release(); tris.release(); attrs.release(); recs.release(); faces.release();
         normals.release(); uvw.release(); tangents.release(); bitangents.release(); materials.release(); texmaps.release();
@@ -1335,7 +1424,7 @@ struct mi355pt_render {
     struct Ev { hipEvent_t a, b; int kind; };
     std::vector<Ev> events; bool ev_open = false;
     double ms[4] = {0, 0, 0, 0}; uint64_t extend_launches = 0;
-    int grid = 2048, extend_grid = 768; TraceShape shape{1, 0, 0}; uint32_t stack_entries = 8, node_lanes = kNodeLanes, owner_lanes = 64, setup_min = 32;
+    int grid = 2048, extend_grid = 768; TraceShape shape{1, 0, 0}; uint32_t stack_entries = 8, node_lanes = kNodeLanes, owner_lanes = 64, setup_min = 32; bool no_analytic_vis = false;
     ~mi355pt_render() {
         for (auto& e : events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
         for (hipEvent_t e : fork) (void)hipEventDestroy(e);
@@ -1591,6 +1680,7 @@ int mi355pt_scene_create(const mi355pt_scene_desc* desc, int32_t device, mi355pt
         }
     }
     sc->num_tris = tris.size() / 3; sc->num_bvh_nodes = bvh_nodes.size() / 4;
+    sc->analytic_only = desc->num_models == 0;
     // ---- walk records (pt_scene.h), in the reference's visiting order
     std::vector<float4> recs;
     std::vector<int> inst_rec(insts.size() + 1, 0);
@@ -1910,6 +2000,7 @@ int mi355pt_render_create(mi355pt_scene* scene, const mi355pt_render_params* par
     }
     // test knobs: results must not depend on either (tests/test_gpu_parity.py::test_traversal_schedule_*)
     if (const char* e = getenv("MI355PT_NODE_LANES")) r->node_lanes = (uint32_t)std::min(64, std::max(1, atoi(e)));
+    r->no_analytic_vis = getenv("MI355PT_NO_ANALYTIC_VIS") != nullptr;
     if (const char* e = getenv("MI355PT_SETUP_MIN")) r->setup_min = (uint32_t)std::min(40, std::max(1, atoi(e)));
     if (const char* e = getenv("MI355PT_OWNER_LANES")) r->owner_lanes = (uint32_t)std::min(64, std::max(1, atoi(e)));
     r->count_work = getenv("MI355PT_COUNT_WORK") != nullptr;
@@ -2069,11 +2160,15 @@ int run_paths(mi355pt_render* r, uint32_t n, uint32_t jitter = 1, uint32_t only_
             HIP_TRY(hipStreamWaitEvent(vs, r->fork[b], 0));
         }
         ev_begin(r, 2, vs);
-        if (r->scene->model_lights) {                       // lights on Models: their own-object sweep first
-            launch_trace<2>(r->count_work, (size_t)ge, r->shape, vs, S, P, prm, b, n);
+        if (r->scene->analytic_only && !r->no_analytic_vis) {       // no Models: both visibility sweeps and the combination in one pass
+            hipLaunchKernelGGL(k_vis_connect, dim3(g), dim3(kBlock), 0, vs, S, P, b);
+        } else {
+            if (r->scene->model_lights) {                   // lights on Models: their own-object sweep first
+                launch_trace<2>(r->count_work, (size_t)ge, r->shape, vs, S, P, prm, b, n);
+            }
+            launch_trace<1>(r->count_work, (size_t)ge, r->shape, vs, S, P, prm, b, n);
+            hipLaunchKernelGGL(k_connect, dim3(g), dim3(kBlock), 0, vs, S, P, b);
         }
-        launch_trace<1>(r->count_work, (size_t)ge, r->shape, vs, S, P, prm, b, n);
-        hipLaunchKernelGGL(k_connect, dim3(g), dim3(kBlock), 0, vs, S, P, b);
         ev_end(r, vs);
         if (fork) { HIP_TRY(hipEventRecord(r->join[b], vs)); pending = true; last_fork = b; }
         else if (b + 1 < nbounce) closest(b + 1);

@@ -616,6 +616,33 @@ def test_material_atlas_same_results(built, monkeypatch):
     p3.close_render()
 
 
+@pytest.mark.parametrize("name", ["cornell_c1", "cornell_c3_dof", "cornell_spheres", "env_sphere"])
+def test_analytic_visibility_pass_same_results(built, name, monkeypatch):
+    """Scenes without a Model (Planes and Spheres only) run both visibility sweeps and k_connect's combination as ONE
+    streaming pass (k_vis_connect) instead of k_trace<ANY> + k_connect.  MI355PT_NO_ANALYTIC_VIS (read at renderer
+    creation) switches back: same per-sample radiance, accumulators and ray counts, bit for bit."""
+    s, orc, pt, w, h = built(name)
+    rng = np.random.default_rng(29)
+    pixel = rng.integers(0, w * h, 4000).astype(np.uint32)
+    sample = rng.integers(0, 32, 4000).astype(np.uint32)
+    a, _ = pt.sample_radiance(pixel, sample)
+    pt.Init(w, h); pt.reset_stats(); pt.step(3); pt.sync()
+    ma, ca = pt.read_accum()
+    sa = pt.stats()
+    monkeypatch.setenv("MI355PT_NO_ANALYTIC_VIS", "1")
+    p2 = PathTracer(pt.dscene)
+    monkeypatch.delenv("MI355PT_NO_ANALYTIC_VIS")
+    p2.Init(w, h)
+    b, _ = p2.sample_radiance(pixel, sample)
+    p2.Init(w, h); p2.reset_stats(); p2.step(3); p2.sync()
+    mb, cb = p2.read_accum()
+    sb = p2.stats()
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    assert np.array_equal(ma.view(np.uint32), mb.view(np.uint32)) and np.array_equal(ca, cb)
+    assert sa["shadow_rays"] == sb["shadow_rays"] > 0 and sa["closest_rays"] == sb["closest_rays"]
+    p2.close_render()
+
+
 @pytest.mark.parametrize("name", ["teapot_cornell", "stress_layout", "textured_c2", "cornell_spheres"])
 def test_shade_tables_in_lds_same_results(built, name, monkeypatch):
     """k_shade<KIND, ATLAS, TABLES>: scenes whose instance / node / material / light tables fit 12 KB get a copy of them
