@@ -1121,6 +1121,41 @@ __global__ void __launch_bounds__(kBlock) k_connect(DScene S, DPaths P, uint32_t
     wave_add64(rays, &P.stat[1]);
 }
 
+// ---------------------------------------------------------------------- closest hit for scenes without Models
+// TraceNode's sweep over Planes and Spheres (raytracer.cpp:189-258) as a streaming pass, one lane per ray, the walk records in
+// LDS: what k_trace<closest> does for such a scene in its set-up phase alone (see k_vis_connect).
+__global__ void __launch_bounds__(kBlock) k_closest_analytic(DScene S, DPaths P, Params prm, uint32_t bounce, uint32_t n0) {
+    const uint32_t n = bounce == 0 ? n0 : P.counts[bounce];
+    const uint32_t* q = bounce == 0 ? nullptr : P.queue[bounce & 1];
+    if (blockIdx.x == 0 && threadIdx.x == 0 && P.progress) {       // the host's early stop reads this bounce's queue length (run_paths)
+        __hip_atomic_store(&P.progress[bounce], ((unsigned long long)prm.gen << 32) | (unsigned long long)(n + 1u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    __shared__ float4 recl[kRecCache * kRecStride];
+    const uint32_t ncache = (uint32_t)S.num_recs < kRecCache ? (uint32_t)S.num_recs : kRecCache;
+    for (uint32_t k = threadIdx.x; k < ncache * kRecStride; k += blockDim.x) recl[k] = S.recs[k];
+    __syncthreads();
+    auto to_obj = [&](auto R, uint32_t inst, const Ray& wr) { return rec_ray(S, R, __float_as_uint(R[0].y), inst, wr, 1u); };
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const uint32_t slot = q ? ((const PT_GLOBAL_AS uint32_t*)q)[i] : i;
+        Ray wr; wr.p = xyz(P.ray[2 * (size_t)slot]); wr.d = xyz(P.ray[2 * (size_t)slot + 1]);
+        if (S.num_recs > 0) wr = rec_ray(S, (const float4*)recl, 1u, 0u, wr);
+        float best_t = kBig; int best_inst = -1;
+        for (uint32_t rec = 0; rec < (uint32_t)S.num_recs;) {
+            const uint32_t cur = rec;
+            float4 h0, h1;
+            if (cur < ncache) { h0 = recl[cur * kRecStride]; h1 = recl[cur * kRecStride + 1]; }
+            else { const float4* R = S.recs + (size_t)cur * kRecStride; h0 = R[0]; h1 = R[1]; }
+            const uint32_t kind = __float_as_uint(h0.x), rii = __float_as_uint(h1.x);
+            rec = __float_as_uint(h0.z);
+            const Ray lr = cur < ncache ? to_obj((const float4*)(recl + cur * kRecStride), rii, wr) : to_obj(S.recs + (size_t)cur * kRecStride, rii, wr);
+            float t; bool front; F3 Pp;
+            const bool hit = kind == MI355PT_OBJ_PLANE ? plane_hit(lr.p, lr.d, SIDE_BOTH, t, front, Pp) : sphere_hit(lr.p, lr.d, SIDE_BOTH, t, front, Pp);
+            if (hit && t < best_t) { best_t = t; best_inst = (int)rii; }      // an earlier object wins ties (raytracer.cpp:208)
+        }
+        store_hit(P, slot, best_t, best_inst, -1, 0u);
+    }
+}
+
 // ---------------------------------------------------------------------- visibility + connect for scenes without Models
 // A scene of Planes and Spheres only (C1, C3: the Cornell boxes) has no BVH to traverse: a visibility item is a sweep over a
 // handful of walk records.  k_trace<ANY> runs that sweep in its set-up phase -- the persistent-wave machinery around it (leaf
@@ -2106,7 +2141,8 @@ int run_paths(mi355pt_render* r, uint32_t n, uint32_t jitter = 1, uint32_t only_
         pb.use_prep = (b < r->prep_bounces && use_prepass(r, n)) ? 1u : 0u;
         if (pb.use_prep && !(b == 0 && prep0_done)) hipLaunchKernelGGL(k_prepare, dim3(g), dim3(kBlock), 0, r->stream, S, P, b, n);
         ev_begin(r, 0, r->stream);
-        launch_trace<0>(r->count_work, (size_t)ge, r->shape, r->stream, S, P, pb, b, n);
+        if (r->scene->analytic_only && !r->no_analytic_vis) hipLaunchKernelGGL(k_closest_analytic, dim3(g), dim3(kBlock), 0, r->stream, S, P, pb, b, n);
+        else launch_trace<0>(r->count_work, (size_t)ge, r->shape, r->stream, S, P, pb, b, n);
         ev_end(r, r->stream);
     };
     const uint32_t nbounce = only_extend ? 0u : p.max_bounces;
