@@ -813,6 +813,74 @@ __global__ void __launch_bounds__(kExtBlockMax) k_trace(DScene S, DPaths P, Para
         if (MODE == 0 && lane == 0) atomicAdd(&P.stat[14], n_drain_act); }
 }
 
+// ---------------------------------------------------------------------- NEE + MIS of one vertex in a scene without Models
+// LightVisTest (raytracer.cpp:67-152) for the light sample (direction wi1, distance `dist`) and the MIS BRDF sample (wi2) of
+// a vertex, as sweeps over the walk records -- the record walk and arithmetic of k_trace<ANY>'s set-up -- followed by
+// k_connect's combination.  `recl`: the first `ncache` records in LDS.  Returns the `direct` term of render.h:148 before the
+// division by the light-selection pdf; counts the LightVisTest calls in `rays`.  Used by k_vis_connect (inputs from the
+// shadow record) and by k_shade's VIS instances (inputs still in registers).
+PT_DEV F3 vis_direct(const DScene& S, const float4* recl, uint32_t ncache, const DLight& L, uint32_t flags, F3 so, float dist, F3 wi1, F3 wi2,
+                     float mis_lz, F3 c1, float pdf2, F3 A2, float mis_pdf, F3 hp, unsigned long long& rays) {
+    const uint32_t linst = (uint32_t)L.inst;
+    // one call per address space (a selected pointer would make every record read a flat load)
+    auto to_obj = [&](auto R, uint32_t inst, const Ray& wr) { return rec_ray(S, R, __float_as_uint(R[0].y), inst, wr, 1u); };
+    auto to_obj_at = [&](uint32_t rec, uint32_t inst, const Ray& wr) {
+        return rec < ncache ? to_obj(recl + rec * kRecStride, inst, wr) : to_obj(S.recs + (size_t)rec * kRecStride, inst, wr);
+    };
+    bool blocked[2] = {false, false};
+    for (uint32_t which = 0; which < 2u; which++) {
+        if (!(flags & (1u << which))) continue;
+        rays++;
+        Ray wr; wr.p = so; wr.d = which ? wi2 : wi1;
+        if (S.num_recs > 0) wr = rec_ray(S, recl, 1u, 0u, wr);
+        // (1) the light's own object, both sides: a miss or its back side blocks (raytracer.cpp:67-97, 138-145)
+        const float tmax = which ? kBig : dist;
+        float lz = 0.0f; bool front = false, hit;
+        if (S.plane_lights_only && which) { hit = true; front = true; lz = mis_lz; }          // the MIS ray was tested by k_shade
+        else {
+            const Ray lr = to_obj_at((uint32_t)L.rec, linst, wr);
+            F3 Pp;
+            hit = L.kind == MI355PT_OBJ_PLANE ? plane_hit(lr.p, lr.d, SIDE_BOTH, lz, front, Pp) : sphere_hit(lr.p, lr.d, SIDE_BOTH, lz, front, Pp);
+        }
+        if (!hit || !front) { blocked[which] = true; continue; }
+        const float bound = tmax < lz ? tmax : lz;                    // (2) an occluder blocks iff z < tmax && z < lightZ
+        for (uint32_t rec = 0; rec < (uint32_t)S.num_recs;) {
+            const uint32_t cur = rec;
+            float4 h0, h1;
+            if (cur < ncache) { h0 = recl[cur * kRecStride]; h1 = recl[cur * kRecStride + 1]; }
+            else { const float4* R = S.recs + (size_t)cur * kRecStride; h0 = R[0]; h1 = R[1]; }
+            const uint32_t kind = __float_as_uint(h0.x), nexti = __float_as_uint(h0.z);
+            const uint32_t rii = __float_as_uint(h1.x);
+            rec = nexti;
+            if (rii == linst) continue;                               // the light's own object is not an occluder
+            const Ray lr = to_obj_at(cur, rii, wr);
+            float t; bool fr; F3 Pp;
+            const bool oh = kind == MI355PT_OBJ_PLANE ? plane_hit(lr.p, lr.d, SIDE_FRONT, t, fr, Pp) : sphere_hit(lr.p, lr.d, SIDE_FRONT, t, fr, Pp);
+            if (oh && t < bound) { blocked[which] = true; break; }
+        }
+    }
+    // ---- k_connect's combination
+    F3 direct = f3(0, 0, 0);
+    if ((flags & 1u) && !blocked[0]) direct = direct + c1;
+    if ((flags & 2u) && !blocked[1]) {
+        float lightPdf;
+        if (S.plane_lights_only) lightPdf = mis_pdf;
+        else {
+            Ray r; r.p = so; r.d = wi2;
+            F3 lp, ln;
+            HitRec mh; mh.t = 0.0f; mh.inst = -1; mh.mesh = -1; mh.slot = 0;
+            light_hit_point(S, r, L, mh, lp, ln);
+            lightPdf = light_pdf(L, hp, lp, ln, len(lp - hp));
+        }
+        if (!(lightPdf <= 0.0f)) {
+            const float pb = pdf2;
+            const float w = (pb * pb) / (pb * pb + lightPdf * lightPdf);
+            direct = direct + A2 * w / pb;
+        }
+    }
+    return direct;
+}
+
 // ---------------------------------------------------------------------- shade
 // RenderPixel's loop body for one bounce (render.h:121-206) minus the two visibility traces, which are
 // queued for k_trace<ANY> / k_connect.  One workgroup = one wave.  Shading is instruction-bound (thousands
@@ -830,7 +898,9 @@ constexpr int kShadeBlock = 64;
 // KIND: the material model this instance shades (MI355PT_MTL_DISNEY / _STANDARD: two code bodies, disneyMaterial.h:85-203 and
 // standardMaterial.h:33-103): hits on the other kind are left to the other instance's launch, and only the instance with
 // `do_miss` finishes the misses.  A scene with one kind of material runs one instance.
-template <int KIND, bool ATLAS, bool TABLES>
+// VIS (scenes without a Model, with TABLES): the vertex's two visibility sweeps and their MIS combination run right here
+// (vis_direct) -- no shadow record, no visibility queue, no k_vis_connect launch.
+template <int KIND, bool ATLAS, bool TABLES, bool VIS = false>
 __global__ void __launch_bounds__(kShadeBlock) __attribute__((amdgpu_waves_per_eu(KIND == MI355PT_MTL_STANDARD ? PT_SHADE_WAVES_STD : PT_SHADE_WAVES, 8)))
 k_shade(DScene S, DCamera cam, DPaths P, Params prm, uint32_t bounce, uint32_t n0, uint32_t do_miss, uint32_t lds_tables) {
     // The way from a hit record to its surface is a chain of dependent per-lane loads from small tables: instance -> node chain
@@ -857,6 +927,16 @@ k_shade(DScene S, DCamera cam, DPaths P, Params prm, uint32_t bounce, uint32_t n
         S.insts = (const DInst*)tables; S.nodes = (const DNodeXf*)(tables + ni);
         S.materials = (const mi355pt_material*)(tables + ni + nn);
         S.lights = (const DLight*)(tables + ni + nn + nm);
+    }
+    const float4* recl = nullptr; uint32_t nrc = 0;                  // VIS: the first walk records, behind the four tables
+    if (TABLES && VIS) {
+        const uint32_t ni = (uint32_t)S.num_insts * (uint32_t)sizeof(DInst) / 16u, nn = ((uint32_t)S.num_nodes * (uint32_t)sizeof(DNodeXf) + 15u) / 16u;
+        const uint32_t nm = ((uint32_t)S.num_materials * (uint32_t)sizeof(mi355pt_material) + 15u) / 16u, nl = (uint32_t)S.num_lights * (uint32_t)sizeof(DLight) / 16u;
+        nrc = (uint32_t)S.num_recs < kRecCache ? (uint32_t)S.num_recs : kRecCache;
+        float4* dst = tables + ni + nn + nm + nl;
+        for (uint32_t k = threadIdx.x; k < nrc * kRecStride; k += 64u) dst[k] = S.recs[k];
+        __syncthreads();
+        recl = dst;
     }
     const uint32_t n = bounce == 0 ? n0 : P.counts[bounce];
     const uint32_t* q = bounce == 0 ? nullptr : P.queue[bounce & 1];
@@ -1016,7 +1096,10 @@ k_shade(DScene S, DCamera cam, DPaths P, Params prm, uint32_t bounce, uint32_t n
                             if (!light_hit_point(S, sr, L, none, lp, ln, &mis_lz)) { flags &= ~2u; mis_blocked++; }
                             else mis_pdf = light_pdf(L, h.p, lp, ln, len(lp - h.p));
                         }
-                        if (flags) {
+                        if (VIS && flags) {
+                            const F3 direct = vis_direct(S, recl, nrc, L, flags, h.p + h.N * kBias, dist, wi1, wi2, mis_lz, c1, pdf2, A2, mis_pdf, h.p, mis_blocked);
+                            C = C + T * (direct / selectPdf);          // k_connect's update, at the place in the order of C's updates where it happens
+                        } else if (flags) {
                             const F3 so = h.p + h.N * kBias;
                             float4* sh = P.sh + (size_t)slot * P.shv;
                             sh[SHV_O] = f4(so, dist); sh[SHV_W1] = f4(wi1, __uint_as_float((uint32_t)li | (flags << 28))); sh[SHV_W2] = f4(wi2, mis_lz);
@@ -1172,73 +1255,16 @@ __global__ void __launch_bounds__(kBlock) k_vis_connect(DScene S, DPaths P, uint
     const uint32_t ncache = (uint32_t)S.num_recs < kRecCache ? (uint32_t)S.num_recs : kRecCache;
     for (uint32_t k = threadIdx.x; k < ncache * kRecStride; k += blockDim.x) recl[k] = S.recs[k];
     __syncthreads();
-    // one call per address space (a selected pointer would make every record read a flat load)
-    auto to_obj = [&](auto R, uint32_t inst, const Ray& wr) { return rec_ray(S, R, __float_as_uint(R[0].y), inst, wr, 1u); };
-    auto to_obj_at = [&](uint32_t rec, uint32_t inst, const Ray& wr) {
-        return rec < ncache ? to_obj((const float4*)(recl + rec * kRecStride), inst, wr) : to_obj(S.recs + (size_t)rec * kRecStride, inst, wr);
-    };
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const uint32_t slot = P.squeue[i];
         const float4* sh = P.sh + (size_t)slot * P.shv;
-        const float4 o4 = sh[SHV_O], w1 = sh[SHV_W1], w2 = sh[SHV_W2], c1 = sh[SHV_C1], a2 = sh[SHV_A2];
+        const float4 o4 = sh[SHV_O], w1 = sh[SHV_W1], w2 = sh[SHV_W2], c1 = sh[SHV_C1], a2 = sh[SHV_A2], tb = sh[SHV_TB];
         const uint32_t flags = __float_as_uint(w1.w) >> 28;
         const DLight& L = S.lights[__float_as_uint(w1.w) & kShLightMask];
-        const uint32_t linst = (uint32_t)L.inst;
-        bool blocked[2] = {false, false};
-        for (uint32_t which = 0; which < 2u; which++) {
-            if (!(flags & (1u << which))) continue;
-            rays++;
-            Ray wr; wr.p = xyz(o4); wr.d = which ? xyz(w2) : xyz(w1);
-            if (S.num_recs > 0) wr = rec_ray(S, (const float4*)recl, 1u, 0u, wr);
-            // (1) the light's own object, both sides: a miss or its back side blocks (raytracer.cpp:67-97, 138-145)
-            const float tmax = which ? kBig : o4.w;
-            float lz = 0.0f; bool front = false, hit;
-            if (S.plane_lights_only && which) { hit = true; front = true; lz = w2.w; }          // the MIS ray was tested by k_shade
-            else {
-                const Ray lr = to_obj_at((uint32_t)L.rec, linst, wr);
-                F3 Pp;
-                hit = L.kind == MI355PT_OBJ_PLANE ? plane_hit(lr.p, lr.d, SIDE_BOTH, lz, front, Pp) : sphere_hit(lr.p, lr.d, SIDE_BOTH, lz, front, Pp);
-            }
-            if (!hit || !front) { blocked[which] = true; continue; }
-            const float bound = tmax < lz ? tmax : lz;                    // (2) an occluder blocks iff z < tmax && z < lightZ
-            for (uint32_t rec = 0; rec < (uint32_t)S.num_recs;) {
-                const uint32_t cur = rec;
-                float4 h0, h1;
-                if (cur < ncache) { h0 = recl[cur * kRecStride]; h1 = recl[cur * kRecStride + 1]; }
-                else { const float4* R = S.recs + (size_t)cur * kRecStride; h0 = R[0]; h1 = R[1]; }
-                const uint32_t kind = __float_as_uint(h0.x), nexti = __float_as_uint(h0.z);
-                const uint32_t rii = __float_as_uint(h1.x);
-                rec = nexti;
-                if (rii == linst) continue;                               // the light's own object is not an occluder
-                const Ray lr = to_obj_at(cur, rii, wr);
-                float t; bool fr; F3 Pp;
-                const bool oh = kind == MI355PT_OBJ_PLANE ? plane_hit(lr.p, lr.d, SIDE_FRONT, t, fr, Pp) : sphere_hit(lr.p, lr.d, SIDE_FRONT, t, fr, Pp);
-                if (oh && t < bound) { blocked[which] = true; break; }
-            }
-        }
-        // ---- k_connect's combination
-        F3 direct = f3(0, 0, 0);
-        if ((flags & 1u) && !blocked[0]) direct = direct + xyz(c1);
-        if ((flags & 2u) && !blocked[1]) {
-            float lightPdf;
-            if (S.plane_lights_only) lightPdf = sh[SHV_TB].w;
-            else {
-                Ray r; r.p = xyz(o4); r.d = xyz(w2);
-                F3 lp, ln;
-                HitRec mh; mh.t = 0.0f; mh.inst = -1; mh.mesh = -1; mh.slot = 0;
-                light_hit_point(S, r, L, mh, lp, ln);
-                const F3 hp = xyz(sh[SHV_HP]);
-                lightPdf = light_pdf(L, hp, lp, ln, len(lp - hp));
-            }
-            if (!(lightPdf <= 0.0f)) {
-                const float pb = c1.w;
-                const float w = (pb * pb) / (pb * pb + lightPdf * lightPdf);
-                direct = direct + xyz(a2) * w / pb;
-            }
-        }
-        const F3 Tb = xyz(sh[SHV_TB]);
+        const F3 hp = S.plane_lights_only ? f3(0, 0, 0) : xyz(sh[SHV_HP]);
+        const F3 direct = vis_direct(S, (const float4*)recl, ncache, L, flags, xyz(o4), o4.w, xyz(w1), xyz(w2), w2.w, xyz(c1), c1.w, xyz(a2), tb.w, hp, rays);
         F3 C = xyz(P.C[slot]);
-        C = C + Tb * (direct / a2.w);
+        C = C + xyz(tb) * (direct / a2.w);
         P.C[slot] = f4(C, 0.0f);
     }
     wave_add64(rays, &P.stat[1]);
@@ -2170,9 +2196,15 @@ int run_paths(mi355pt_render* r, uint32_t n, uint32_t jitter = 1, uint32_t only_
         const uint32_t kinds = r->scene->mtl_kinds ? r->scene->mtl_kinds : 1u;
         // (... and per "the scene has material atlases": the instances without that code keep their registers)
         const uint32_t miss2 = (kinds & 1u) ? 0u : 1u;
-        const uint32_t tb = shade_table_bytes(S, r->scene->no_shade_tables);
+        uint32_t tb = shade_table_bytes(S, r->scene->no_shade_tables);
+        // scenes without a Model: visibility and its combination inside k_shade (needs the tables in LDS; the atlas instances do without)
+        const bool vis_inline = r->scene->analytic_only && !r->no_analytic_vis && !S.mtl_atlas && tb > 0;
+        if (vis_inline) tb += (uint32_t)std::min<size_t>((size_t)S.num_recs, kRecCache) * kRecStride * 16u;
         auto shade = [&](auto kern, uint32_t miss) { hipLaunchKernelGGL(kern, dim3(gs), dim3(kShadeBlock), tb, r->stream, S, r->cam, P, prm, b, n, miss, tb); };
-        if (S.mtl_atlas && tb) {
+        if (vis_inline) {
+            if (kinds & 1u) shade(k_shade<MI355PT_MTL_DISNEY, false, true, true>, 1u);
+            if (kinds & 2u) shade(k_shade<MI355PT_MTL_STANDARD, false, true, true>, miss2);
+        } else if (S.mtl_atlas && tb) {
             if (kinds & 1u) shade(k_shade<MI355PT_MTL_DISNEY, true, true>, 1u);
             if (kinds & 2u) shade(k_shade<MI355PT_MTL_STANDARD, true, true>, miss2);
         } else if (S.mtl_atlas) {
@@ -2196,7 +2228,8 @@ int run_paths(mi355pt_render* r, uint32_t n, uint32_t jitter = 1, uint32_t only_
             HIP_TRY(hipStreamWaitEvent(vs, r->fork[b], 0));
         }
         ev_begin(r, 2, vs);
-        if (r->scene->analytic_only && !r->no_analytic_vis) {       // no Models: both visibility sweeps and the combination in one pass
+        if (vis_inline) {                                           // no Models: k_shade<.., VIS> has done it all
+        } else if (r->scene->analytic_only && !r->no_analytic_vis) {       // ... or, with an atlas / without LDS tables: both sweeps and the combination in one pass
             hipLaunchKernelGGL(k_vis_connect, dim3(g), dim3(kBlock), 0, vs, S, P, b);
         } else {
             if (r->scene->model_lights) {                   // lights on Models: their own-object sweep first

@@ -619,8 +619,8 @@ def test_material_atlas_same_results(built, monkeypatch):
 @pytest.mark.parametrize("name", ["cornell_c1", "cornell_c3_dof", "cornell_spheres", "env_sphere"])
 def test_analytic_visibility_pass_same_results(built, name, monkeypatch):
     """Scenes without a Model (Planes and Spheres only) run the closest-hit sweep as a streaming pass (k_closest_analytic)
-    and both visibility sweeps with k_connect's combination as ONE streaming pass (k_vis_connect) instead of the
-    k_trace kernels + k_connect.  MI355PT_NO_ANALYTIC_VIS (read at renderer
+    and both visibility sweeps with k_connect's combination inside k_shade (the VIS instances, vis_direct; textured_c2-like
+    scenes with an atlas would take the streaming pass k_vis_connect) instead of the k_trace kernels + k_connect.  MI355PT_NO_ANALYTIC_VIS (read at renderer
     creation) switches back: same per-sample radiance, accumulators and ray counts, bit for bit."""
     s, orc, pt, w, h = built(name)
     rng = np.random.default_rng(29)
