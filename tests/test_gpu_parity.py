@@ -642,6 +642,20 @@ def test_analytic_visibility_pass_same_results(built, name, monkeypatch):
     assert np.array_equal(ma.view(np.uint32), mb.view(np.uint32)) and np.array_equal(ca, cb)
     assert sa["shadow_rays"] == sb["shadow_rays"] > 0 and sa["closest_rays"] == sb["closest_rays"]
     p2.close_render()
+    # without the LDS tables k_shade cannot hold the records: the streaming pass k_vis_connect does the visibility instead
+    from pathtracer_amd import DeviceScene
+    monkeypatch.setenv("MI355PT_NO_SHADE_TABLES", "1")
+    p3 = PathTracer(DeviceScene(s))
+    monkeypatch.delenv("MI355PT_NO_SHADE_TABLES")
+    p3.Init(w, h)
+    c, _ = p3.sample_radiance(pixel, sample)
+    p3.Init(w, h); p3.reset_stats(); p3.step(3); p3.sync()
+    mc, cc = p3.read_accum()
+    sc = p3.stats()
+    assert np.array_equal(a.view(np.uint32), c.view(np.uint32))
+    assert np.array_equal(ma.view(np.uint32), mc.view(np.uint32)) and np.array_equal(ca, cc)
+    assert sa["shadow_rays"] == sc["shadow_rays"]
+    p3.close_render()
 
 
 @pytest.mark.parametrize("name", ["teapot_cornell", "stress_layout", "textured_c2", "cornell_spheres"])
