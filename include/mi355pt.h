@@ -208,6 +208,8 @@ typedef struct mi355pt_stats {
     uint64_t debug[8];          /* counting builds: kernel-internal utilisation counters */
     uint64_t shaded_vertices;   /* k_shade: path vertices shaded (hits)                 */
     uint64_t texture_taps;      /* k_shade: bilinear texture lookups (32 per map with ray differentials, else 1) */
+    uint64_t shadow_rays_traversed; /* LightVisTest calls that entered a visibility kernel (the others were decided in k_shade:
+                                       the MIS ray missing the light's own plane; they still count in shadow_rays)          */
 } mi355pt_stats;
 
 typedef struct mi355pt_scene  mi355pt_scene;    /* opaque: flattened scene in HBM      */
@@ -220,7 +222,9 @@ typedef struct mi355pt_render mi355pt_render;   /* opaque: accumulator + path qu
  * that still has renderers defers the release to the last mi355pt_render_destroy.  mi355pt_last_error is per thread. */
 
 /* Library / device. */
+#define MI355PT_ABI_VERSION 3      /* 3: mi355pt_stats grew (shadow_rays_traversed), groups / communicators / scene files, lazy path pool */
 const char* mi355pt_version(void);
+int mi355pt_abi_version(void);
 const char* mi355pt_last_error(void);
 /* Number of usable gfx950 devices (0 when none): there is NO CPU fallback. */
 int mi355pt_device_count(void);
@@ -230,6 +234,23 @@ int mi355pt_device_count(void);
  * description, flattens it to the SoA layout of DESIGN.md and uploads it.          */
 int mi355pt_scene_create(const mi355pt_scene_desc* desc, int32_t device, mi355pt_scene** out);
 void mi355pt_scene_destroy(mi355pt_scene* scene);
+
+/* One host build, N uploads (no reference counterpart as API; the reference builds a mesh's BVH once and looks it up by
+ * path, BVHManager, include/bvh.h:818-841).  The description is validated and flattened ONCE -- BVH build, walk records,
+ * triangle slots, attribute records -- and the result is uploaded to each of `devices` (ordinals may repeat); `out` receives
+ * num_devices scenes, each destroyed with mi355pt_scene_destroy.  On failure every scene already created is destroyed. */
+int mi355pt_scene_create_multi(const mi355pt_scene_desc* desc, const int32_t* devices, uint32_t num_devices, mi355pt_scene** out);
+
+/* The same split across processes (one rank per GPU): mi355pt_scene_save flattens `desc` on the host -- no GPU needed -- and
+ * writes the result to `path` (written under a temporary name and renamed: a reader never sees a partial file);
+ * mi355pt_scene_load maps the file read-only and uploads it to `device` without building anything.  Ranks that load share
+ * the file's pages, so the host cost of an N-rank job is one build and one copy of the flattened scene, not N.
+ * MI355PT_SAVE_TREES also stores the pointer trees mi355pt_scene_get_bvh exports (40 B per BVH node); without it that
+ * call returns MI355PT_ERR_UNSUPPORTED on a loaded scene.  Files are tied to the library build that wrote them
+ * (record layouts are hashed into the header); a mismatch is MI355PT_ERR_INVALID. */
+#define MI355PT_SAVE_TREES 1u
+int mi355pt_scene_save(const mi355pt_scene_desc* desc, const char* path, uint32_t flags);
+int mi355pt_scene_load(const char* path, int32_t device, mi355pt_scene** out);
 
 /* Export of the BVH the library holds for `mesh` in the reference's pointer-tree
  * form, for node-for-node comparison with MeshBVHNew (include/bvh.h:257-530).
@@ -300,7 +321,12 @@ int mi355pt_trace_visibility(mi355pt_render* render, const float* origins, const
                              int32_t light, uint32_t count, uint8_t* blocked);
 
 int mi355pt_render_stats(mi355pt_render* render, mi355pt_stats* stats);
+/* The same for a caller compiled against an older (shorter) or newer mi355pt_stats: writes min(struct_bytes, sizeof(mi355pt_stats))
+ * bytes -- fields are only ever appended.  mi355pt_abi_version() (below) says which header the library was built from. */
+int mi355pt_render_stats_sized(mi355pt_render* render, void* stats, uint32_t struct_bytes);
 int mi355pt_render_reset_stats(mi355pt_render* render);
+/* The parameters a renderer was created with (image size, splits, seed). */
+int mi355pt_render_get_params(mi355pt_render* render, mi355pt_render_params* params);
 
 /* Measurement switches (no reference counterpart): enable_events = 1 brackets every k_trace<closest>
  * launch (the dominant kernel) with HIP events on the stream it is launched on, 2 brackets every stage
@@ -329,6 +355,55 @@ int mi355pt_render_set_overlap(mi355pt_render* render, uint32_t from_bounce);
 #define MI355PT_STATIC_MAX_RAYS 131072u
 int mi355pt_trace_rays_static(mi355pt_scene* scene, const float* d_origins, const float* d_dirs, uint32_t count,
                               int32_t* d_node, int32_t* d_mesh, int32_t* d_face, float* d_t, void* stream);
+
+/* ---------------------------------------------------------------- multi-GPU
+ * No counterpart as API in the reference, whose workers are std::threads over one image (src/pathtracer.cpp:23-35, 66-109:
+ * worker i renders pixels i, i + T, ...).  Here the workers are GPUs.  Every (pixel, sample) is independent given the
+ * immutable scene, so the path shards with no data-path collective; the scene is flattened ONCE on the host and uploaded
+ * to every device; the work is split
+ *   MI355PT_SPLIT_SAMPLE  by sample index: shard g of G renders samples g, g + G, ... of every pixel, or
+ *   MI355PT_SPLIT_TILE    by image tile: tile k of the row-major grid of 64x64 tiles goes to shard k mod G (interleaved,
+ *                         like the reference's strided workers);
+ * and because the reference averages tone-mapped samples (pathtracer.cpp:84-86) a pixel is linear in its samples: the
+ * read-out is ONE ncclReduce(sum, float) of 4 floats per pixel -- (n * mean, n) for the sample split, (mean of the owner,
+ * n) for the tile split, which is exact -- to the first device (RCCL over xGMI; librccl.so.1 is loaded on first use).
+ *
+ * mi355pt_group: one process, several GPUs -- what a drop-in PathTracer on the reference's single tracing thread
+ * (src/raytracer.cpp:436-439, src/window.cpp:140-150) uses to drive all 8 GPUs of a node.  `devices` lists one HIP ordinal
+ * per shard; an ordinal may repeat (several shards on one GPU share its scene and are added locally before the reduce).
+ * `params` is the template of every shard's renderer (its device / sample_* / tile_* fields are filled per shard, composing
+ * with the caller's own split if it has one).  mi355pt_group_step(spp) makes every shard render `spp` samples of each of
+ * its pixels -- the image gains G * spp samples per pixel under the sample split, spp under the tile split -- on one host
+ * thread per shard.  read_rgb8 / read_accum wait for the step in flight, combine, and return the whole image; with a
+ * single shard (and no MI355PT_GROUP_FORCE_RCCL) they are that shard's own accumulator, bit for bit.                      */
+#define MI355PT_SPLIT_SAMPLE 0
+#define MI355PT_SPLIT_TILE   1
+#define MI355PT_GROUP_FORCE_RCCL 1u    /* run the packed reduce through RCCL even with one device (exercises the collective on a 1-GPU box) */
+typedef struct mi355pt_group mi355pt_group;
+int mi355pt_group_create(const mi355pt_scene_desc* desc, const int32_t* devices, uint32_t num_shards, const mi355pt_render_params* params,
+                         int32_t split, uint32_t flags, mi355pt_group** out);
+void mi355pt_group_destroy(mi355pt_group* group);
+int mi355pt_group_step(mi355pt_group* group, uint32_t spp);
+int mi355pt_group_sync(mi355pt_group* group);
+int mi355pt_group_read_rgb8(mi355pt_group* group, uint8_t* rgb);
+int mi355pt_group_read_accum(mi355pt_group* group, float* mean_rgb, uint32_t* count);
+int mi355pt_group_stats(mi355pt_group* group, mi355pt_stats* sum);       /* counters summed over the shards, stage times = the slowest shard's */
+uint32_t mi355pt_group_size(const mi355pt_group* group);
+mi355pt_render* mi355pt_group_render(mi355pt_group* group, uint32_t shard);   /* a shard's renderer, for the parity hooks and switches */
+double mi355pt_group_readout_ms(const mi355pt_group* group);              /* wall time of the last combine (pack, reduce, unpack) */
+
+/* One process per GPU (torchrun, MPI): every rank creates its own scene (mi355pt_scene_load of one shared file) and
+ * renderer with its share of the split in mi355pt_render_params; rank 0 calls mi355pt_comm_unique_id and hands the 128
+ * bytes to the others by whatever channel the job has; every rank then calls mi355pt_comm_create (collective) and, at
+ * read-out, mi355pt_render_reduce (collective): the same packed reduce as above, to `root`, whose host buffers
+ * (any may be NULL; ignored on the other ranks) receive the combined mean, sample counts and RGB8 frame.            */
+#define MI355PT_COMM_ID_BYTES 128
+typedef struct mi355pt_comm mi355pt_comm;
+int mi355pt_comm_unique_id(uint8_t id[MI355PT_COMM_ID_BYTES]);
+int mi355pt_comm_create(const uint8_t id[MI355PT_COMM_ID_BYTES], int32_t rank, int32_t nranks, int32_t device, mi355pt_comm** out);
+void mi355pt_comm_destroy(mi355pt_comm* comm);
+int mi355pt_render_reduce(mi355pt_render* render, mi355pt_comm* comm, int32_t root, int32_t split,
+                          float* mean_rgb, uint32_t* count, uint8_t* rgb8, double* device_ms);
 
 /* The renderer's main stream (hipStream_t): every step begins and ends on it (the second stream's
  * work is joined into it before the step's last kernel), so an event recorded on it after

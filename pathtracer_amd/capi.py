@@ -88,7 +88,7 @@ class Stats(C.Structure):
     _fields_ = [("closest_rays", u64), ("shadow_rays", u64), ("samples", u64), ("bvh_node_visits", u64),
                 ("bvh_tri_tests", u64), ("shadow_node_visits", u64), ("shadow_tri_tests", u64), ("max_nodes_per_ray", u64), ("extend_ms", C.c_double), ("shade_ms", C.c_double),
                 ("connect_ms", C.c_double), ("other_ms", C.c_double), ("extend_launches", u64), ("debug", u64 * 8),
-                ("shaded_vertices", u64), ("texture_taps", u64)]
+                ("shaded_vertices", u64), ("texture_taps", u64), ("shadow_rays_traversed", u64)]
 
 
 def make_params(width, height, seed=0x5EED, max_bounces=30, rr_start=3, sample_offset=0, sample_stride=1, device=0,
@@ -106,7 +106,17 @@ SYMBOLS = [
     "mi355pt_render_accum_device_ptrs", "mi355pt_trace_primary", "mi355pt_trace_rays", "mi355pt_sample_radiance",
     "mi355pt_render_stats", "mi355pt_render_reset_stats", "mi355pt_render_set_profiling", "mi355pt_render_set_overlap", "mi355pt_render_stream",
     "mi355pt_trace_rays_static", "mi355pt_trace_visibility",
+    "mi355pt_abi_version", "mi355pt_scene_create_multi", "mi355pt_scene_save", "mi355pt_scene_load",
+    "mi355pt_render_stats_sized", "mi355pt_render_get_params",
+    "mi355pt_group_create", "mi355pt_group_destroy", "mi355pt_group_step", "mi355pt_group_sync", "mi355pt_group_read_rgb8",
+    "mi355pt_group_read_accum", "mi355pt_group_stats", "mi355pt_group_size", "mi355pt_group_render", "mi355pt_group_readout_ms",
+    "mi355pt_comm_unique_id", "mi355pt_comm_create", "mi355pt_comm_destroy", "mi355pt_render_reduce",
 ]
+ABI_VERSION = 3
+SPLIT_SAMPLE, SPLIT_TILE = 0, 1
+GROUP_FORCE_RCCL = 1
+SAVE_TREES = 1
+COMM_ID_BYTES = 128
 STATIC_MAX_RAYS = 131072
 
 _lib = None
@@ -153,6 +163,31 @@ def load_library(path=None):
     lib.mi355pt_render_stream.restype = vp
     lib.mi355pt_trace_visibility.argtypes = [vp, C.c_void_p, C.c_void_p, C.c_void_p, i32, u32, C.c_void_p]
     lib.mi355pt_trace_rays_static.argtypes = [vp, vp, vp, u32, vp, vp, vp, vp, vp]
+    lib.mi355pt_abi_version.restype = C.c_int
+    lib.mi355pt_scene_create_multi.argtypes = [C.POINTER(SceneDesc), C.POINTER(i32), u32, C.POINTER(vp)]
+    lib.mi355pt_scene_save.argtypes = [C.POINTER(SceneDesc), C.c_char_p, u32]
+    lib.mi355pt_scene_load.argtypes = [C.c_char_p, i32, C.POINTER(vp)]
+    lib.mi355pt_render_stats_sized.argtypes = [vp, C.c_void_p, u32]
+    lib.mi355pt_render_get_params.argtypes = [vp, C.POINTER(RenderParams)]
+    lib.mi355pt_group_create.argtypes = [C.POINTER(SceneDesc), C.POINTER(i32), u32, C.POINTER(RenderParams), i32, u32, C.POINTER(vp)]
+    lib.mi355pt_group_destroy.argtypes = [vp]
+    lib.mi355pt_group_destroy.restype = None
+    lib.mi355pt_group_step.argtypes = [vp, u32]
+    lib.mi355pt_group_sync.argtypes = [vp]
+    lib.mi355pt_group_read_rgb8.argtypes = [vp, C.c_void_p]
+    lib.mi355pt_group_read_accum.argtypes = [vp, C.c_void_p, C.c_void_p]
+    lib.mi355pt_group_stats.argtypes = [vp, C.POINTER(Stats)]
+    lib.mi355pt_group_size.argtypes = [vp]
+    lib.mi355pt_group_size.restype = u32
+    lib.mi355pt_group_render.argtypes = [vp, u32]
+    lib.mi355pt_group_render.restype = vp
+    lib.mi355pt_group_readout_ms.argtypes = [vp]
+    lib.mi355pt_group_readout_ms.restype = C.c_double
+    lib.mi355pt_comm_unique_id.argtypes = [C.c_void_p]
+    lib.mi355pt_comm_create.argtypes = [C.c_void_p, i32, i32, i32, C.POINTER(vp)]
+    lib.mi355pt_comm_destroy.argtypes = [vp]
+    lib.mi355pt_comm_destroy.restype = None
+    lib.mi355pt_render_reduce.argtypes = [vp, vp, i32, i32, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_double)]
     if path is None:
         _lib = lib
     return lib

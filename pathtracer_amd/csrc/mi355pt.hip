@@ -24,6 +24,7 @@
 #include "../../include/mi355pt.h"
 #include "bvh_build.h"
 #include "pt_device.h"
+#include "pt_host.h"
 #include "pt_scene.h"
 #include "pt_shade.h"
 
@@ -1396,29 +1397,19 @@ uint32_t shade_table_bytes(const DScene& S, bool no_tables) {
     return b <= 12288 ? (uint32_t)b : 0u;
 }
 
-thread_local std::string g_err;
-int fail(int code, const std::string& msg) { g_err = msg; return code; }
-#define HIP_TRY(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return fail(MI355PT_ERR_HIP, std::string(#x) + ": " + hipGetErrorString(e_)); } while (0)
+using pth::fail;
 
 template <typename T>
 struct DevBuf {
     T* p = nullptr; size_t n = 0;
     hipError_t alloc(size_t count) { n = count; return hipMalloc((void**)&p, std::max<size_t>(count, 1) * sizeof(T) + 16); }     // + 16: k_shade's table copy reads whole 16-B pieces
-    hipError_t upload(const std::vector<T>& v) {
-        hipError_t e = alloc(v.size()); if (e != hipSuccess) return e;
-        if (!v.empty()) e = hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice);
+    hipError_t upload(const T* v, size_t count) {
+        hipError_t e = alloc(count); if (e != hipSuccess) return e;
+        if (count) e = hipMemcpy(p, v, count * sizeof(T), hipMemcpyHostToDevice);
         return e;
     }
     void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
 };
-
-// host fp32 helpers (same expression trees as the device / reference)
-struct H3 { float x, y, z; };
-H3 h_m4mulp(const float* c, H3 p, float w) {
-    return H3{(p.x * c[0] + p.z * c[8]) + (p.y * c[4] + w * c[12]), (p.x * c[1] + p.z * c[9]) + (p.y * c[5] + w * c[13]),
-              (p.x * c[2] + p.z * c[10]) + (p.y * c[6] + w * c[14])};
-}
-float h_len(H3 a) { return sqrtf(a.x * a.x + a.y * a.y + a.z * a.z); }
 
 }  // namespace
 
@@ -1430,10 +1421,10 @@ static unsigned char* g_scratch_ptr[kMaxDevices] = {nullptr};
 struct mi355pt_scene {
     int device = 0;
     unsigned char* static_scratch = nullptr;     // this device's copy of `scratch`
-    uint32_t static_entries = 8; TraceShape static_shape{1, 0, 0};
+    uint32_t static_entries = 8, static_node_lanes = kNodeLanes, static_setup_min = 32, static_no_cull = 0; TraceShape static_shape{1, 0, 0};
     DScene d{};
     mi355pt_camera camera{};
-    std::vector<ptb::MeshTree> trees;
+    std::shared_ptr<std::vector<ptb::MeshTree>> trees;     // the pointer trees, for mi355pt_scene_get_bvh (absent in a scene loaded from a file saved without them)
     DevBuf<DNodeXf> nodes; DevBuf<DInst> insts; DevBuf<DModel> models; DevBuf<DMesh> meshes;
     DevBuf<float4> bvh_nodes, tris, attrs, recs; DevBuf<uint32_t> faces; DevBuf<float> normals, uvw, tangents, bitangents;
     DevBuf<mi355pt_material> materials; DevBuf<mi355pt_texmap> texmaps; DevBuf<DTexture> textures; DevBuf<DAtlas> atlases; DevBuf<int> mtl_atlas; DevBuf<DLight> lights; DevBuf<float> light_data;
@@ -1449,7 +1440,7 @@ struct mi355pt_scene {
     ~mi355pt_scene() {
         nodes.release(); insts.release(); models.release(); meshes.release(); bvh_nodes.release(); tris.release(); attrs.release(); recs.release(); faces.release();
         normals.release(); uvw.release(); tangents.release(); bitangents.release(); materials.release(); texmaps.release();
-        textures.release(); lights.release(); light_data.release();
+        textures.release(); atlases.release(); mtl_atlas.release(); lights.release(); light_data.release();
         for (void* p : tex_data) (void)hipFree(p);
     }
 };
@@ -1476,6 +1467,9 @@ struct mi355pt_render {
     uint32_t prep_bounces = 0;                      // bounces whose closest-hit trace is fed by k_prepare (the large ones)
     uint32_t prep_min_paths = 1u << 22;             // ... in runs of at least this many paths (MI355PT_PREP_MIN_PATHS)
     void* ctr = nullptr; size_t ctr_bytes = 0;      // the per-bounce counters of DPaths, one block
+    size_t pool_oom_at = 0;                         // smallest pool size the device refused (not retried)
+    size_t pool_limit = 0;                          // most path slots the pool may hold (MI355PT_MAX_PATHS); P.cap = what it holds now
+    std::vector<void*> pool_allocs;                 // the path pool's arrays (ensure_pool)
     std::vector<void*> allocs;
     float* mean = nullptr; uint32_t* cnt = nullptr; uint8_t* rgb8 = nullptr;
     uint32_t* own = nullptr; size_t n_own = 0;       // tile split: the pixels this renderer renders (nullptr = all)
@@ -1491,6 +1485,7 @@ struct mi355pt_render {
         for (hipEvent_t e : fork) (void)hipEventDestroy(e);
         for (hipEvent_t e : join) (void)hipEventDestroy(e);
         for (void* p : allocs) (void)hipFree(p);
+        for (void* p : pool_allocs) (void)hipFree(p);
         if (hook) (void)hipFree(hook);
         if (side) (void)hipStreamDestroy(side);
         if (progress) (void)hipHostFree(progress);
@@ -1549,8 +1544,9 @@ DCamera init_camera(const mi355pt_camera& c, uint32_t w, uint32_t h) {      // I
 // ====================================================================== C ABI
 extern "C" {
 
-const char* mi355pt_version(void) { return "mi355pt 0.1 (gfx950)"; }
-const char* mi355pt_last_error(void) { return g_err.c_str(); }
+const char* mi355pt_version(void) { return "mi355pt 0.3 (gfx950)"; }
+int mi355pt_abi_version(void) { return MI355PT_ABI_VERSION; }
+const char* mi355pt_last_error(void) { return pth::last_error(); }
 
 int mi355pt_device_count(void) {
     int n = 0;
@@ -1563,305 +1559,69 @@ int mi355pt_device_count(void) {
     return ok;
 }
 
-int mi355pt_scene_create(const mi355pt_scene_desc* desc, int32_t device, mi355pt_scene** out) {
-    if (!desc || !out || !desc->nodes || desc->num_nodes == 0) return fail(MI355PT_ERR_INVALID, "null scene description");
+}  // extern "C"
+
+namespace {
+
+// One flattened scene (pt_host.h) -> one GPU.  The view's pages may be a HostScene in memory or a mapped scene file.
+int upload_scene(const pth::SceneView& v, int32_t device, std::shared_ptr<std::vector<ptb::MeshTree>> trees, mi355pt_scene** out) {
     if (int rc = check_device(device)) return rc;
     HIP_TRY(hipSetDevice(device));
+    for (unsigned b = 0; b < 256; b++) {                     // u8_unorm_selftest (pt_shade.h): the division-free byte -> float is exact
+        volatile float q = (float)b / 255.0f;
+        if (ptd::u8_unorm(b) != q) return fail(MI355PT_ERR_HIP, "u8_unorm differs from v / 255.0f");
+    }
     std::unique_ptr<mi355pt_scene> sc(new mi355pt_scene());
-    sc->device = device; sc->camera = desc->camera;
-
-    // ---- nodes, instances (object-bearing nodes in depth-first pre-order = array order)
-    std::vector<DNodeXf> nodes(desc->num_nodes);
-    std::vector<DInst> insts;
-    std::vector<int> inst_of_node(desc->num_nodes, -1);
-    for (uint32_t i = 0; i < desc->num_nodes; i++) {
-        const mi355pt_node& s = desc->nodes[i];
-        if (i == 0 ? s.parent != -1 : (s.parent < 0 || (uint32_t)s.parent >= i)) return fail(MI355PT_ERR_INVALID, "nodes must be in depth-first pre-order");
-        DNodeXf& d = nodes[i];
-        memcpy(d.tm, s.tm, sizeof(d.tm)); memcpy(d.itm, s.itm, sizeof(d.itm)); memcpy(d.pos, s.pos, sizeof(d.pos));
-        memcpy(d.l2w, s.local_to_world, sizeof(d.l2w));
-        d.material = s.material; d.light = s.light; d.pad0 = d.pad1 = 0;
-        // Node::GetLight() <-> LightComponent::parent must point at each other: the kernels index lights[] with node.light
-        if (s.light < -1 || s.light >= (int32_t)desc->num_lights) return fail(MI355PT_ERR_INVALID, "node.light out of range");
-        if (s.light >= 0 && (!desc->lights || desc->lights[s.light].node != (int32_t)i)) return fail(MI355PT_ERR_INVALID, "lights[node.light].node must be that node");
-        if (s.object_kind == MI355PT_OBJ_NONE) continue;
-        if (s.object_kind != MI355PT_OBJ_PLANE && s.object_kind != MI355PT_OBJ_SPHERE && s.object_kind != MI355PT_OBJ_MODEL) return fail(MI355PT_ERR_UNSUPPORTED, "unknown object kind");
-        if (s.material < 0 || (uint32_t)s.material >= desc->num_materials) return fail(MI355PT_ERR_INVALID, "object node without material");
-        if (s.object_kind == MI355PT_OBJ_MODEL && (s.object_index < 0 || (uint32_t)s.object_index >= desc->num_models)) return fail(MI355PT_ERR_INVALID, "bad model index");
-        DInst in{}; in.node = (int)i; in.kind = s.object_kind; in.model = s.object_index; in.material = s.material; in.light = s.light;
-        std::vector<int> chain;
-        for (int c = (int)i; c >= 0; c = desc->nodes[c].parent) chain.push_back(c);
-        if (chain.size() > MI355PT_MAX_CHAIN) return fail(MI355PT_ERR_TOO_LARGE, "scene graph deeper than MI355PT_MAX_CHAIN");
-        in.chain_len = (int)chain.size();
-        for (int k = 0; k < in.chain_len; k++) in.chain[k] = chain[chain.size() - 1 - k];
-        inst_of_node[i] = (int)insts.size();
-        insts.push_back(in);
-    }
-    for (unsigned v = 0; v < 256; v++) {                     // u8_unorm_selftest (pt_shade.h): the division-free byte -> float is exact
-        volatile float q = (float)v / 255.0f;
-        if (ptd::u8_unorm(v) != q) return fail(MI355PT_ERR_HIP, "u8_unorm differs from v / 255.0f");
-    }
-    // ---- lights
-    // Object::Sample / Area of the light's object as the reference computes them (include/mi355pt.h, mi355pt_light)
-    std::vector<DLight> lights(desc->num_lights);
-    std::vector<float> light_data;
-    bool model_lights = false;
-    for (uint32_t i = 0; i < desc->num_lights; i++) {
-        const mi355pt_light& s = desc->lights[i];
-        if (s.node < 0 || (uint32_t)s.node >= desc->num_nodes || desc->nodes[s.node].object_kind == MI355PT_OBJ_NONE)
-            return fail(MI355PT_ERR_INVALID, "a light's node must carry an object (LightComponent::parent->GetNodeObj())");
-        if (desc->nodes[s.node].light != (int32_t)i) return fail(MI355PT_ERR_INVALID, "nodes[light.node].light must be that light");
-        const mi355pt_node& ln = desc->nodes[s.node];
-        DLight& d = lights[i];
-        memset(&d, 0, sizeof(d));
-        d.node = s.node; memcpy(d.intensity, s.intensity, sizeof(d.intensity)); d.inst = inst_of_node[s.node]; d.kind = ln.object_kind;
-        const float* m = ln.local_to_world;
-        auto span = [&](float e) {                                // |X| * |Y| of the node's local axes scaled by e, in world space
-            const H3 zero = h_m4mulp(m, H3{0, 0, 0}, 1.0f), wv = h_m4mulp(m, H3{e, 0, 0}, 1.0f), hv = h_m4mulp(m, H3{0, e, 0}, 1.0f);
-            return h_len(H3{wv.x - zero.x, wv.y - zero.y, wv.z - zero.z}) * h_len(H3{hv.x - zero.x, hv.y - zero.y, hv.z - zero.z});
-        };
-        if (ln.object_kind == MI355PT_OBJ_PLANE) d.area = span(2.0f);            // Plane::Area, objects.cpp:496-503
-        else if (ln.object_kind == MI355PT_OBJ_SPHERE) d.area = 0.0f;            // Object::Area, objbase.h:37-39
-        else {                                                                   // Model::Area, model.h:57-67
-            if (ln.object_index < 0 || (uint32_t)ln.object_index >= desc->num_models) return fail(MI355PT_ERR_INVALID, "bad model index");
-            const mi355pt_model& mo = desc->models[ln.object_index];
-            if (mo.first_mesh < 0 || mo.num_meshes < 1 || (uint32_t)(mo.first_mesh + mo.num_meshes) > desc->num_meshes) return fail(MI355PT_ERR_INVALID, "a light's model needs at least one mesh");
-            model_lights = true;
-            d.data = (int)light_data.size();
-            float total = (+0.0f);
-            light_data.push_back(0.0f); d.n_cd = 1;
-            std::vector<float> face0;
-            for (int k = 0; k < mo.num_meshes; k++) {
-                const mi355pt_mesh& me = desc->meshes[mo.first_mesh + k];
-                if (!me.vertices || !me.faces || me.num_faces < 1) return fail(MI355PT_ERR_INVALID, "a light's meshes need at least one face (Mesh::SampleFace(0))");
-                auto vert = [&](uint32_t f, int c) { const uint32_t v = me.faces[4 * (size_t)f + c]; return H3{me.vertices[3 * (size_t)v], me.vertices[3 * (size_t)v + 1], me.vertices[3 * (size_t)v + 2]}; };
-                for (uint32_t f = 0; f < me.num_faces; f++) for (int c = 0; c < 3; c++) if (me.faces[4 * (size_t)f + c] >= me.num_vertices) return fail(MI355PT_ERR_INVALID, "face index out of range");
-                if (mo.flags & MI355PT_MODEL_HAS_CDF) {          // BuildCDFAndArea, model.h:47-55 / mesh.h:63-83 (glm cross, length)
-                    float area = 0.0f;
-                    for (uint32_t f = 0; f < me.num_faces; f++) {
-                        const H3 p0 = vert(f, 0), p1 = vert(f, 1), p2 = vert(f, 2);
-                        const H3 x = H3{p1.x - p0.x, p1.y - p0.y, p1.z - p0.z}, y = H3{p2.x - p0.x, p2.y - p0.y, p2.z - p0.z};
-                        const H3 c = H3{x.y * y.z - y.y * x.z, x.z * y.x - y.z * x.x, x.x * y.y - y.x * x.y};
-                        area += 0.5f * sqrtf(c.x * c.x + c.y * c.y + c.z * c.z);
-                    }
-                    total += area; light_data.push_back(total); d.n_cd++;
-                }
-                for (int c = 0; c < 3; c++) { const H3 p = vert(0, c); face0.push_back(p.x); face0.push_back(p.y); face0.push_back(p.z); }
-            }
-            light_data.insert(light_data.end(), face0.begin(), face0.end());
-            d.area = span(1.0f) * total;
+    const pth::Header& H = v.h;
+    sc->device = device; sc->camera = H.camera; sc->trees = std::move(trees);
+    sc->model_lights = H.model_lights != 0; sc->mtl_kinds = H.mtl_kinds; sc->no_shade_tables = H.no_shade_tables != 0;
+    sc->analytic_only = H.analytic_only != 0; sc->num_tris = H.num_tris; sc->num_bvh_nodes = H.num_bvh_nodes; sc->max_depth = H.max_depth;
+    size_t n_nodes, n_insts, n_models, n_meshes, n_bvh, n_tris, n_attrs, n_recs, n_faces, n_normals, n_uvw, n_tan, n_bit, n_mtl, n_tm, n_tex, n_atl, n_ma, n_li, n_ld;
+    const DNodeXf* nodes = v.ptr<DNodeXf>(pth::S_NODES, &n_nodes); const DInst* insts = v.ptr<DInst>(pth::S_INSTS, &n_insts);
+    const DModel* models = v.ptr<DModel>(pth::S_MODELS, &n_models); const DMesh* meshes = v.ptr<DMesh>(pth::S_MESHES, &n_meshes);
+    const float4* bvh = v.ptr<float4>(pth::S_BVH, &n_bvh); const float4* tris = v.ptr<float4>(pth::S_TRIS, &n_tris);
+    const float4* attrs = v.ptr<float4>(pth::S_ATTRS, &n_attrs); const float4* recs = v.ptr<float4>(pth::S_RECS, &n_recs);
+    const uint32_t* faces = v.ptr<uint32_t>(pth::S_FACES, &n_faces); const float* normals = v.ptr<float>(pth::S_NORMALS, &n_normals);
+    const float* uvw = v.ptr<float>(pth::S_UVW, &n_uvw); const float* tangents = v.ptr<float>(pth::S_TANGENTS, &n_tan); const float* bitangents = v.ptr<float>(pth::S_BITANGENTS, &n_bit);
+    const mi355pt_material* materials = v.ptr<mi355pt_material>(pth::S_MATERIALS, &n_mtl); const mi355pt_texmap* texmaps = v.ptr<mi355pt_texmap>(pth::S_TEXMAPS, &n_tm);
+    const DTexture* textures = v.ptr<DTexture>(pth::S_TEXTURES, &n_tex); const DAtlas* atlases = v.ptr<DAtlas>(pth::S_ATLASES, &n_atl);
+    const int* mtl_atlas = v.ptr<int>(pth::S_MTL_ATLAS, &n_ma); const DLight* lights = v.ptr<DLight>(pth::S_LIGHTS, &n_li); const float* light_data = v.ptr<float>(pth::S_LIGHT_DATA, &n_ld);
+    if (!nodes || n_nodes == 0) return fail(MI355PT_ERR_INVALID, "scene without nodes");
+    // texels: one allocation per texture / atlas; the tables get the device pointers
+    std::vector<DTexture> tex(textures, textures + n_tex);
+    for (size_t i = 0; i < n_tex; i++) {
+        const pth::Section* px = v.find(pth::S_TEXPIX, (uint32_t)i);
+        tex[i].data = nullptr;
+        if (px && px->bytes) {
+            void* p; HIP_TRY(hipMalloc(&p, px->bytes)); sc->tex_data.push_back(p);
+            HIP_TRY(hipMemcpy(p, px->p, px->bytes, hipMemcpyHostToDevice)); tex[i].data = p;
         }
     }
-    sc->model_lights = model_lights;
-    // ---- meshes: BVH build / import, flatten, pack
-    std::vector<DModel> models(desc->num_models);
-    for (uint32_t i = 0; i < desc->num_models; i++) {
-        const mi355pt_model& s = desc->models[i];
-        if (s.first_mesh < 0 || s.num_meshes < 0 || (uint32_t)(s.first_mesh + s.num_meshes) > desc->num_meshes) return fail(MI355PT_ERR_INVALID, "bad model mesh range");
-        memcpy(models[i].aabb, s.aabb, sizeof(s.aabb)); models[i].first_mesh = s.first_mesh; models[i].num_meshes = s.num_meshes;
+    std::vector<DAtlas> atl(atlases, atlases + n_atl);
+    for (size_t i = 0; i < n_atl; i++) {
+        const pth::Section* px = v.find(pth::S_ATLASPIX, (uint32_t)i);
+        if (!px || !px->bytes) return fail(MI355PT_ERR_INVALID, "material atlas without texels");
+        void* p; HIP_TRY(hipMalloc(&p, px->bytes)); sc->tex_data.push_back(p);
+        HIP_TRY(hipMemcpy(p, px->p, px->bytes, hipMemcpyHostToDevice)); atl[i].data = (const uint2*)p;
     }
-    std::vector<DMesh> meshes(desc->num_meshes);
-    std::vector<float4> bvh_nodes, tris, attrs;
-    std::vector<uint32_t> faces; std::vector<float> normals, uvw, tangents, bitangents;
-    sc->trees.resize(desc->num_meshes);
-    uint32_t top_base = 0, top_count = 0, top_faces = 0;      // the BVH top k_trace keeps in LDS: that of the mesh with most triangles
-    const int threads = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
-    for (uint32_t mi = 0; mi < desc->num_meshes; mi++) {
-        const mi355pt_mesh& s = desc->meshes[mi];
-        if (!s.vertices || !s.faces || !s.normals || !s.uvw) return fail(MI355PT_ERR_INVALID, "mesh needs vertices, normals, uvw and faces");
-        for (size_t k = 0; k < (size_t)s.num_faces; k++)
-            for (int c = 0; c < 3; c++) if (s.faces[4 * k + c] >= s.num_vertices) return fail(MI355PT_ERR_INVALID, "face index out of range");
-        ptb::MeshTree& tree = sc->trees[mi];
-        if (s.bvh_nodes && s.num_bvh_nodes) {
-            if (!ptb::import_tree(s.bvh_nodes, s.num_bvh_nodes, s.bvh_faces, s.num_bvh_faces, s.num_faces, tree)) return fail(MI355PT_ERR_INVALID, "malformed BVH in mesh");
-        } else {
-            ptb::build_tree(s.vertices, s.faces, s.num_faces, s.aabb, threads, tree);
-        }
-        if (tree.max_depth + 4 > kStackSize) return fail(MI355PT_ERR_TOO_LARGE, "BVH deeper than the traversal stack");
-        sc->max_depth = std::max(sc->max_depth, tree.max_depth);
-        ptb::FlatMesh flat;
-        ptb::flatten_tree(tree, flat);
-        DMesh& d = meshes[mi];
-        memcpy(d.aabb, s.aabb, sizeof(d.aabb)); memcpy(d.root_bound, tree.nodes[0].bound, sizeof(d.root_bound));
-        const uint32_t node_base = (uint32_t)(bvh_nodes.size() / 4), tri_base = (uint32_t)(tris.size() / 3);
-        if ((uint64_t)tri_base + flat.slot_face.size() > (uint64_t)kLeafSlotMask) return fail(MI355PT_ERR_TOO_LARGE, "more than 2^27 triangles");
-        d.face_base = (uint32_t)(faces.size() / 4); d.vert_base = (uint32_t)(normals.size() / 3);
-        d.has_tangents = (s.tangents && s.bitangents) ? 1 : 0; d.pad = 0;
-        if (flat.top_records > 0 && s.num_faces > top_faces) { top_faces = s.num_faces; top_base = node_base; top_count = flat.top_records; }
-        const bool root_internal = flat.root_cnt >= ptb::kChain;
-        d.root_ref = root_internal ? node_base : tri_base + flat.root_ref; d.root_cnt = flat.root_cnt;
-        // node records: rebase references to the global pools
-        const size_t nrec = flat.node_words.size() / 16;
-        bvh_nodes.resize(bvh_nodes.size() + 4 * nrec);
-        for (size_t r = 0; r < nrec; r++) {
-            float w[16]; memcpy(w, &flat.node_words[16 * r], sizeof(w));
-            // the device form of the two children (k_trace's node step): word 12 / 13 = record index of a node child (> 0;
-            // a chain record's box becomes [-inf, +inf]: entered whatever the ray), or the ready-made leaf-queue item of a
-            // leaf child (bit 31 set), or 0 for a leaf without triangles; words 14 / 15 unused
-            uint32_t u[4]; memcpy(u, &w[12], sizeof(u));
-            for (int c = 0; c < 2; c++) {
-                const uint32_t cnt = u[2 + c];
-                if (cnt >= ptb::kChain) {
-                    u[c] += node_base;
-                    if (u[c] == 0u || u[c] >= 0x80000000u) return fail(MI355PT_ERR_TOO_LARGE, "node record index out of range");
-                    if (cnt == ptb::kChain) for (int a = 0; a < 3; a++) { w[6 * c + a] = -INFINITY; w[6 * c + 3 + a] = INFINITY; }
-                } else if (cnt == 0u) u[c] = 0u;
-                else u[c] = kLeafFlag | ((cnt - 1u) << 27) | (u[c] + tri_base);
-            }
-            u[2] = u[3] = 0u;
-            memcpy(&w[12], u, sizeof(u));
-            memcpy(&bvh_nodes[4 * ((size_t)node_base + r)], w, sizeof(w));
-        }
-        // triangle slots: v0 v1 v2 + position of the face in faces[]
-        tris.resize(tris.size() + 3 * flat.slot_face.size());
-        attrs.resize(attrs.size() + 5 * flat.slot_face.size());
-        for (size_t k = 0; k < flat.slot_face.size(); k++) {
-            const uint32_t fpos = flat.slot_face[k];
-            const uint32_t* f = s.faces + 4 * (size_t)fpos;
-            const float* a = s.vertices + 3 * (size_t)f[0]; const float* b = s.vertices + 3 * (size_t)f[1]; const float* c = s.vertices + 3 * (size_t)f[2];
-            float4* t = &tris[3 * ((size_t)tri_base + k)];
-            t[0] = make_float4(a[0], a[1], a[2], b[0]); t[1] = make_float4(b[1], b[2], c[0], c[1]);
-            float fid; memcpy(&fid, &fpos, 4);
-            t[2] = make_float4(c[2], fid, 0.0f, 0.0f);
-            // shading attributes by slot too: the winning triangle's normals / uvw come with one load level instead of
-            // slot -> face -> vertex indices -> normals (three dependent round trips in k_shade)
-            float av[20] = {0};
-            for (int c3 = 0; c3 < 3; c3++)
-                for (int e = 0; e < 3; e++) { av[3 * c3 + e] = s.normals[3 * (size_t)f[c3] + e]; av[9 + 3 * c3 + e] = s.uvw[3 * (size_t)f[c3] + e]; }
-            float4* at = &attrs[5 * ((size_t)tri_base + k)];
-            for (int q = 0; q < 5; q++) at[q] = make_float4(av[4 * q], av[4 * q + 1], av[4 * q + 2], av[4 * q + 3]);
-        }
-        faces.insert(faces.end(), s.faces, s.faces + 4 * (size_t)s.num_faces);
-        normals.insert(normals.end(), s.normals, s.normals + 3 * (size_t)s.num_vertices);
-        uvw.insert(uvw.end(), s.uvw, s.uvw + 3 * (size_t)s.num_vertices);
-        if (d.has_tangents) {
-            tangents.resize(3 * (size_t)d.face_base, 0.0f); bitangents.resize(3 * (size_t)d.face_base, 0.0f);
-            tangents.insert(tangents.end(), s.tangents, s.tangents + 3 * (size_t)s.num_faces);
-            bitangents.insert(bitangents.end(), s.bitangents, s.bitangents + 3 * (size_t)s.num_faces);
-        }
-    }
-    sc->num_tris = tris.size() / 3; sc->num_bvh_nodes = bvh_nodes.size() / 4;
-    sc->analytic_only = desc->num_models == 0;
-    // ---- walk records (pt_scene.h), in the reference's visiting order
-    std::vector<float4> recs;
-    std::vector<int> inst_rec(insts.size() + 1, 0);
-    auto f_of = [](uint32_t u) { float f; memcpy(&f, &u, 4); return f; };
-    for (size_t ii = 0; ii < insts.size(); ii++) {
-        const DInst& in = insts[ii];
-        inst_rec[ii] = (int)(recs.size() / kRecStride);
-        const int nrec = in.kind == MI355PT_OBJ_MODEL ? models[in.model].num_meshes : 1;
-        for (int k = 0; k < nrec; k++) {
-            float4 R[kRecStride];
-            memset(R, 0, sizeof(R));
-            const uint32_t next = (uint32_t)(inst_rec[ii] + nrec);
-            R[0] = make_float4(f_of((uint32_t)in.kind), f_of((uint32_t)in.chain_len), f_of(next), f_of(k == 0 ? 1u : 0u));
-            if (in.kind == MI355PT_OBJ_MODEL) {
-                const DModel& mo = models[in.model]; const DMesh& M = meshes[mo.first_mesh + k];
-                uint32_t fl = k == 0 ? 1u : 0u;
-                if (memcmp(mo.aabb, M.aabb, sizeof(M.aabb)) == 0) fl |= 2u;             // same bits -> same slab result
-                if (memcmp(M.aabb, M.root_bound, sizeof(M.aabb)) == 0) fl |= 4u;
-                R[0].w = f_of(fl);
-                R[1] = make_float4(f_of((uint32_t)ii), f_of((uint32_t)k), f_of(M.root_ref), f_of(M.root_cnt));
-                R[2] = make_float4(mo.aabb[0], mo.aabb[1], mo.aabb[2], mo.aabb[3]);
-                R[3] = make_float4(mo.aabb[4], mo.aabb[5], M.aabb[0], M.aabb[1]);
-                R[4] = make_float4(M.aabb[2], M.aabb[3], M.aabb[4], M.aabb[5]);
-                R[5] = make_float4(M.root_bound[0], M.root_bound[1], M.root_bound[2], M.root_bound[3]);
-                R[6] = make_float4(M.root_bound[4], M.root_bound[5], 0.0f, 0.0f);
-            } else R[1] = make_float4(f_of((uint32_t)ii), f_of(0u), f_of(0u), f_of(0u));
-            for (int l = 0; l < in.chain_len && l < kRecLevels; l++) {
-                const DNodeXf& nx = nodes[in.chain[l]];
-                R[7 + 3 * l] = make_float4(nx.itm[0], nx.itm[1], nx.itm[2], nx.itm[3]);
-                R[8 + 3 * l] = make_float4(nx.itm[4], nx.itm[5], nx.itm[6], nx.itm[7]);
-                R[9 + 3 * l] = make_float4(nx.itm[8], nx.pos[0], nx.pos[1], nx.pos[2]);
-            }
-            recs.insert(recs.end(), R, R + kRecStride);
-        }
-    }
-    inst_rec[insts.size()] = (int)(recs.size() / kRecStride);
-    for (auto& L : lights) { L.rec = L.inst >= 0 ? inst_rec[L.inst] : 0; L.rec_end = L.inst >= 0 ? inst_rec[L.inst + 1] : 0; }
-    // ---- materials / textures
-    std::vector<mi355pt_material> materials(desc->materials, desc->materials + desc->num_materials);
-    std::vector<mi355pt_texmap> texmaps(desc->texmaps, desc->texmaps + desc->num_texmaps);
-    for (auto& m : materials) {
-        if (m.kind != MI355PT_MTL_DISNEY && m.kind != MI355PT_MTL_STANDARD) return fail(MI355PT_ERR_UNSUPPORTED, "unknown material kind");
-        sc->mtl_kinds |= m.kind == MI355PT_MTL_DISNEY ? 1u : 2u;
-    }
-    auto bad_map = [&](int m) { return m >= (int)desc->num_texmaps; };
-    for (auto& m : materials) if (bad_map(m.albedo_map) || bad_map(m.roughness_map) || bad_map(m.metalness_map) || bad_map(m.normal_map)) return fail(MI355PT_ERR_INVALID, "bad texmap index");
-    for (auto& m : texmaps) if (m.texture >= (int)desc->num_textures) return fail(MI355PT_ERR_INVALID, "bad texture index");
-    if (bad_map(desc->env_map)) return fail(MI355PT_ERR_INVALID, "bad environment map index");
-    std::vector<DTexture> textures(desc->num_textures);
-    for (uint32_t i = 0; i < desc->num_textures; i++) {
-        const mi355pt_texture& s = desc->textures[i]; DTexture& d = textures[i];
-        d.kind = s.kind; d.width = s.width; d.height = s.height; d.pad = 0; d.data = nullptr;
-        memcpy(d.c1, s.color1, sizeof(d.c1)); memcpy(d.c2, s.color2, sizeof(d.c2));
-        const size_t n = (size_t)s.width * s.height;
-        if (s.kind == MI355PT_TEX_RGB8 && s.data && n) {           // padded to RGBA8 for aligned 4-byte texel loads
-            std::vector<uchar4> px(n); const uint8_t* b = (const uint8_t*)s.data;
-            for (size_t k = 0; k < n; k++) px[k] = make_uchar4(b[3 * k], b[3 * k + 1], b[3 * k + 2], 255);
-            void* p; HIP_TRY(hipMalloc(&p, n * sizeof(uchar4))); sc->tex_data.push_back(p);
-            HIP_TRY(hipMemcpy(p, px.data(), n * sizeof(uchar4), hipMemcpyHostToDevice)); d.data = p;
-        } else if (s.kind == MI355PT_TEX_RGB32F && s.data && n) {
-            std::vector<float4> px(n); const float* b = (const float*)s.data;
-            for (size_t k = 0; k < n; k++) px[k] = make_float4(b[3 * k], b[3 * k + 1], b[3 * k + 2], 1.0f);
-            void* p; HIP_TRY(hipMalloc(&p, n * sizeof(float4))); sc->tex_data.push_back(p);
-            HIP_TRY(hipMemcpy(p, px.data(), n * sizeof(float4), hipMemcpyHostToDevice)); d.data = p;
-        } else if (s.kind != MI355PT_TEX_CHECKER) { d.width = d.height = 0; }
-    }
-    // ---- material atlases (DAtlas, pt_scene.h): four 8-bit maps of one size under one texture transform -> one 8-B-per-texel copy
-    std::vector<DAtlas> atlases; std::vector<int> mtl_atlas(materials.size(), -1);
-    sc->no_shade_tables = getenv("MI355PT_NO_SHADE_TABLES") != nullptr;
-    if (!getenv("MI355PT_NO_ATLAS")) {
-        std::vector<std::array<int, 4>> keys;
-        for (size_t mi = 0; mi < materials.size(); mi++) {
-            const mi355pt_material& m = materials[mi];
-            const int maps[4] = {m.albedo_map, m.normal_map, m.roughness_map, m.metalness_map};
-            std::array<int, 4> tex{}; bool ok = true;
-            for (int k = 0; k < 4 && ok; k++) {
-                ok = maps[k] >= 0 && texmaps[maps[k]].texture >= 0;
-                if (!ok) break;
-                tex[k] = texmaps[maps[k]].texture;
-                const mi355pt_texture& t = desc->textures[tex[k]], &t0 = desc->textures[tex[0]];
-                ok = t.kind == MI355PT_TEX_RGB8 && t.data && t.width > 0 && t.height > 0 && t.width == t0.width && t.height == t0.height &&
-                     !memcmp(texmaps[maps[k]].itm, texmaps[maps[0]].itm, sizeof(texmaps[0].itm)) && !memcmp(texmaps[maps[k]].pos, texmaps[maps[0]].pos, sizeof(texmaps[0].pos));
-            }
-            if (!ok) continue;
-            size_t found = 0;
-            for (; found < keys.size(); found++) if (keys[found] == tex) break;
-            if (found == keys.size()) {
-                const mi355pt_texture& t0 = desc->textures[tex[0]];
-                const size_t n = (size_t)t0.width * t0.height;
-                const uint8_t* a = (const uint8_t*)desc->textures[tex[0]].data; const uint8_t* nm = (const uint8_t*)desc->textures[tex[1]].data;
-                const uint8_t* ro = (const uint8_t*)desc->textures[tex[2]].data; const uint8_t* me = (const uint8_t*)desc->textures[tex[3]].data;
-                std::vector<uint2> px(n);
-                for (size_t k = 0; k < n; k++)
-                    px[k] = make_uint2((uint32_t)a[3 * k] | (uint32_t)a[3 * k + 1] << 8 | (uint32_t)a[3 * k + 2] << 16 | (uint32_t)nm[3 * k] << 24,
-                                       (uint32_t)nm[3 * k + 1] | (uint32_t)nm[3 * k + 2] << 8 | (uint32_t)ro[3 * k] << 16 | (uint32_t)me[3 * k] << 24);
-                void* p; HIP_TRY(hipMalloc(&p, n * sizeof(uint2))); sc->tex_data.push_back(p);
-                HIP_TRY(hipMemcpy(p, px.data(), n * sizeof(uint2), hipMemcpyHostToDevice));
-                DAtlas A; A.width = t0.width; A.height = t0.height; A.data = (const uint2*)p;
-                atlases.push_back(A); keys.push_back(tex);
-            }
-            mtl_atlas[mi] = (int)found;
-        }
-    }
-    // ---- upload
-    HIP_TRY(sc->nodes.upload(nodes)); HIP_TRY(sc->insts.upload(insts)); HIP_TRY(sc->models.upload(models)); HIP_TRY(sc->meshes.upload(meshes));
-    HIP_TRY(sc->bvh_nodes.upload(bvh_nodes)); HIP_TRY(sc->tris.upload(tris)); HIP_TRY(sc->attrs.upload(attrs)); HIP_TRY(sc->faces.upload(faces));
-    HIP_TRY(sc->normals.upload(normals)); HIP_TRY(sc->uvw.upload(uvw)); HIP_TRY(sc->tangents.upload(tangents)); HIP_TRY(sc->bitangents.upload(bitangents));
-    HIP_TRY(sc->recs.upload(recs));
-    HIP_TRY(sc->materials.upload(materials)); HIP_TRY(sc->texmaps.upload(texmaps)); HIP_TRY(sc->textures.upload(textures)); HIP_TRY(sc->lights.upload(lights));
-    if (!atlases.empty()) { HIP_TRY(sc->atlases.upload(atlases)); HIP_TRY(sc->mtl_atlas.upload(mtl_atlas)); } HIP_TRY(sc->light_data.upload(light_data));
+    HIP_TRY(sc->nodes.upload(nodes, n_nodes)); HIP_TRY(sc->insts.upload(insts, n_insts)); HIP_TRY(sc->models.upload(models, n_models)); HIP_TRY(sc->meshes.upload(meshes, n_meshes));
+    HIP_TRY(sc->bvh_nodes.upload(bvh, n_bvh)); HIP_TRY(sc->tris.upload(tris, n_tris)); HIP_TRY(sc->attrs.upload(attrs, n_attrs)); HIP_TRY(sc->faces.upload(faces, n_faces));
+    HIP_TRY(sc->normals.upload(normals, n_normals)); HIP_TRY(sc->uvw.upload(uvw, n_uvw)); HIP_TRY(sc->tangents.upload(tangents, n_tan)); HIP_TRY(sc->bitangents.upload(bitangents, n_bit));
+    HIP_TRY(sc->recs.upload(recs, n_recs));
+    HIP_TRY(sc->materials.upload(materials, n_mtl)); HIP_TRY(sc->texmaps.upload(texmaps, n_tm)); HIP_TRY(sc->textures.upload(tex.data(), tex.size())); HIP_TRY(sc->lights.upload(lights, n_li));
+    if (n_atl) { HIP_TRY(sc->atlases.upload(atl.data(), atl.size())); HIP_TRY(sc->mtl_atlas.upload(mtl_atlas, n_ma)); }
+    HIP_TRY(sc->light_data.upload(light_data, n_ld));
     DScene& d = sc->d;
-    d.nodes = sc->nodes.p; d.num_nodes = (int)nodes.size(); d.insts = sc->insts.p; d.num_insts = (int)insts.size();
+    d.nodes = sc->nodes.p; d.num_nodes = (int)n_nodes; d.insts = sc->insts.p; d.num_insts = (int)n_insts;
     d.models = sc->models.p; d.meshes = sc->meshes.p; d.bvh_nodes = sc->bvh_nodes.p; d.tris = sc->tris.p; d.attrs = sc->attrs.p; d.faces = sc->faces.p;
     d.normals = sc->normals.p; d.uvw = sc->uvw.p; d.tangents = sc->tangents.p; d.bitangents = sc->bitangents.p;
-    d.materials = sc->materials.p; d.num_materials = (int)materials.size(); d.texmaps = sc->texmaps.p; d.textures = sc->textures.p; d.mtl_atlas = atlases.empty() ? nullptr : sc->mtl_atlas.p; d.atlases = atlases.empty() ? nullptr : sc->atlases.p; d.lights = sc->lights.p; d.num_lights = (int)lights.size(); d.light_data = sc->light_data.p;
-    d.plane_lights_only = 1;
-    for (const DLight& L : lights) if (L.kind != MI355PT_OBJ_PLANE) d.plane_lights_only = 0;
-    d.recs = sc->recs.p; d.num_recs = (int)(recs.size() / kRecStride);
-    d.top_base = top_base; d.top_count = top_count;
-    memcpy(d.env_color, desc->env_color, sizeof(d.env_color)); d.env_map = desc->env_map;
+    d.materials = sc->materials.p; d.num_materials = (int)n_mtl; d.texmaps = sc->texmaps.p; d.textures = sc->textures.p;
+    d.mtl_atlas = n_atl ? sc->mtl_atlas.p : nullptr; d.atlases = n_atl ? sc->atlases.p : nullptr;
+    d.lights = sc->lights.p; d.num_lights = (int)n_li; d.light_data = sc->light_data.p;
+    d.plane_lights_only = (int)H.plane_lights_only;
+    d.recs = sc->recs.p; d.num_recs = (int)(n_recs / kRecStride);
+    d.top_base = H.top_base; d.top_count = H.top_count;
+    memcpy(d.env_color, H.env_color, sizeof(d.env_color)); d.env_map = H.env_map;
     // Texture::Sample tap offsets (scene.h:169-175), host libm like the reference: the same 64 floats for every scene.  They live in
     // constant memory of the device (g_filter_taps, pt_shade.h), not in an array inside DScene: k_shade's TABLES instances change
     // four pointers of their DScene, and a struct with a dynamically indexed array in it lives in scratch memory from then on,
@@ -1887,12 +1647,56 @@ int mi355pt_scene_create(const mi355pt_scene_desc* desc, int32_t device, mi355pt
             g_scratch_ptr[device] = ptr;
         }
         sc->static_scratch = g_scratch_ptr[device];
-        sc->static_entries = 8u;                     // the renderer's default stack window (mi355pt_render_create)
-        sc->static_shape = trace_shape(sc->static_entries, waves_per_workgroup(), top_count);
+        sc->static_entries = 8u;                     // the renderer's default stack window (mi355pt_render_create) and its knobs
+        if (const char* e = getenv("MI355PT_STACK_WINDOW")) sc->static_entries = atoi(e) <= 4 ? 4u : (atoi(e) <= 8 ? 8u : 16u);
+        if (const char* e = getenv("MI355PT_NODE_LANES")) sc->static_node_lanes = (uint32_t)std::min(64, std::max(1, atoi(e)));
+        if (const char* e = getenv("MI355PT_SETUP_MIN")) sc->static_setup_min = (uint32_t)std::min(40, std::max(1, atoi(e)));
+        sc->static_no_cull = getenv("MI355PT_NO_CULL") ? 1u : (getenv("MI355PT_CULL_PLAIN") ? 2u : 0u);
+        sc->static_shape = trace_shape(sc->static_entries, waves_per_workgroup(), H.top_count);
         if (int rc = allow_large_lds()) return rc;
     }
     *out = sc.release();
     return MI355PT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mi355pt_scene_create(const mi355pt_scene_desc* desc, int32_t device, mi355pt_scene** out) {
+    if (!out) return fail(MI355PT_ERR_INVALID, "null argument");
+    return mi355pt_scene_create_multi(desc, &device, 1u, out);
+}
+
+int mi355pt_scene_create_multi(const mi355pt_scene_desc* desc, const int32_t* devices, uint32_t num_devices, mi355pt_scene** out) {
+    if (!desc || !devices || !out || num_devices == 0) return fail(MI355PT_ERR_INVALID, "null argument");
+    for (uint32_t i = 0; i < num_devices; i++) { out[i] = nullptr; if (int rc = check_device(devices[i])) return rc; }      // before the (long) host build
+    pth::HostScene hs;
+    if (int rc = pth::flatten_scene(desc, hs)) return rc;
+    const pth::SceneView v = hs.view(false);
+    for (uint32_t i = 0; i < num_devices; i++) {
+        if (int rc = upload_scene(v, devices[i], hs.trees, &out[i])) {
+            const std::string msg = pth::last_error();
+            for (uint32_t k = 0; k < i; k++) { mi355pt_scene_destroy(out[k]); out[k] = nullptr; }
+            return fail(rc, msg);
+        }
+    }
+    return MI355PT_OK;
+}
+
+int mi355pt_scene_save(const mi355pt_scene_desc* desc, const char* path, uint32_t flags) {
+    if (!desc || !path) return fail(MI355PT_ERR_INVALID, "null argument");
+    pth::HostScene hs;
+    if (int rc = pth::flatten_scene(desc, hs)) return rc;
+    return pth::save_view(hs.view((flags & MI355PT_SAVE_TREES) != 0), path);
+}
+
+int mi355pt_scene_load(const char* path, int32_t device, mi355pt_scene** out) {
+    if (!path || !out) return fail(MI355PT_ERR_INVALID, "null argument");
+    *out = nullptr;
+    pth::MappedScene ms;
+    if (int rc = ms.open(path)) return rc;
+    return upload_scene(ms.v, device, ms.trees, out);
 }
 
 void mi355pt_scene_destroy(mi355pt_scene* scene) {
@@ -1906,9 +1710,11 @@ void mi355pt_scene_destroy(mi355pt_scene* scene) {
 }
 
 int mi355pt_scene_get_bvh(const mi355pt_scene* scene, uint32_t mesh, mi355pt_bvh_node* nodes, uint32_t* num_nodes, uint32_t* faces, uint32_t* num_faces) {
-    if (!scene || mesh >= scene->trees.size() || !num_nodes || !num_faces) return fail(MI355PT_ERR_INVALID, "bad argument");
+    if (!scene || !num_nodes || !num_faces) return fail(MI355PT_ERR_INVALID, "bad argument");
+    if (!scene->trees) return fail(MI355PT_ERR_UNSUPPORTED, "this scene was loaded from a file saved without MI355PT_SAVE_TREES");
+    if (mesh >= scene->trees->size()) return fail(MI355PT_ERR_INVALID, "bad mesh index");
     std::vector<mi355pt_bvh_node> n; std::vector<uint32_t> f;
-    ptb::export_tree(scene->trees[mesh], n, f);
+    ptb::export_tree((*scene->trees)[mesh], n, f);
     if (nodes && faces) {
         if (*num_nodes < n.size() || *num_faces < f.size()) return fail(MI355PT_ERR_INVALID, "buffers too small");
         memcpy(nodes, n.data(), n.size() * sizeof(n[0])); memcpy(faces, f.data(), f.size() * sizeof(uint32_t));
@@ -1967,15 +1773,16 @@ int mi355pt_render_create(mi355pt_scene* scene, const mi355pt_render_params* par
     // cost of a batch -- above all the ~20 late bounces that a few thousand Russian-roulette survivors drag out at one ray's
     // latency each (3.4 of 18 ms for a single 4K sample of C4, profiles/r02b_timeline.txt) -- is paid once per batch.
     // C4, samples per batch 8 / 16 / 24 / 32: 3 320 / 3 413 / 3 445 / 3 468 Mrays/s -- 16 is where the curve flattens.
+    // That is the pool's LIMIT (MI355PT_MAX_PATHS); the pool itself is allocated by the first call that needs it, for the
+    // batch that call asks for (ensure_pool): a renderer stepped one sample at a time holds one frame of slots, not sixteen.
     size_t cap = 134217728;
     if (const char* e = getenv("MI355PT_MAX_PATHS")) cap = std::max<size_t>(65536, strtoull(e, nullptr, 10));
     cap = std::min(cap, std::max<size_t>(npix, 65536) * 64);
     cap = (cap + 63) & ~(size_t)63;
+    r->pool_limit = cap;
     auto dalloc = [&](void** p, size_t bytes) -> hipError_t { hipError_t e = hipMalloc(p, bytes); if (e == hipSuccess) r->allocs.push_back(*p); return e; };
-    DPaths& P = r->P; P.cap = (uint32_t)cap;
-    HIP_TRY(dalloc((void**)&P.id, cap * 16)); HIP_TRY(dalloc((void**)&P.ray, cap * 32)); HIP_TRY(dalloc((void**)&P.T, cap * 16)); HIP_TRY(dalloc((void**)&P.C, cap * 16));
-    HIP_TRY(dalloc((void**)&P.hit, cap * 16)); P.shv = scene->d.plane_lights_only ? (uint32_t)SHV_HP : (uint32_t)kShVec; HIP_TRY(dalloc((void**)&P.sh, cap * 16 * P.shv));
-    HIP_TRY(dalloc((void**)&P.queue[0], cap * 4)); HIP_TRY(dalloc((void**)&P.queue[1], cap * 4)); HIP_TRY(dalloc((void**)&P.squeue, cap * 4));
+    DPaths& P = r->P; P.cap = 0;
+    P.shv = scene->d.plane_lights_only ? (uint32_t)SHV_HP : (uint32_t)kShVec;
     const size_t nb = params->max_bounces + 2;
     {   // the per-bounce counters live in one block: one memset per run instead of five
         const size_t nb8 = (nb + 1) & ~(size_t)1;
@@ -1984,13 +1791,9 @@ int mi355pt_render_create(mi355pt_scene* scene, const mi355pt_render_params* par
         P.svcounts = (unsigned long long*)r->ctr;
         P.counts = (uint32_t*)(P.svcounts + nb8); P.work = P.counts + nb8; P.vwork = P.work + nb8; P.lwork = P.vwork + nb8;
     }
-    HIP_TRY(dalloc((void**)&P.vqueue, cap * 8));
-    if (scene->model_lights) HIP_TRY(dalloc((void**)&P.lhit, cap * 2 * sizeof(uint4)));
     r->prep_bounces = params->rr_start + 2;         // the bounces before Russian roulette has thinned the queues (C4: 5 beats 2, 8 and 30)
     if (const char* e = getenv("MI355PT_PREP_BOUNCES")) r->prep_bounces = (uint32_t)std::max(0, atoi(e));
     if (const char* e = getenv("MI355PT_PREP_MIN_PATHS")) r->prep_min_paths = (uint32_t)std::max(0, atoi(e));
-    if (r->prep_bounces) HIP_TRY(dalloc((void**)&P.prep, cap * 4 * sizeof(float4)));
-    HIP_TRY(dalloc((void**)&P.vis, cap * 2));
     HIP_TRY(dalloc((void**)&P.stat, kNumStat * sizeof(unsigned long long)));
     HIP_TRY(hipMemsetAsync(P.stat, 0, kNumStat * sizeof(unsigned long long), r->stream));
     HIP_TRY(dalloc((void**)&r->mean, npix * 12)); HIP_TRY(dalloc((void**)&r->cnt, npix * 4)); HIP_TRY(dalloc((void**)&r->rgb8, npix * 3));
@@ -2105,6 +1908,51 @@ int ensure_hook(mi355pt_render* r, size_t bytes) {
     return MI355PT_OK;
 }
 #define PT_LOCK(r) std::lock_guard<std::recursive_mutex> lk_((r)->mu)
+
+// The path pool: one slot per in-flight (pixel, sample), 278-310 B each.  Allocated on demand for the batch a call asks for,
+// never beyond pool_limit.  When the device cannot give that much (another renderer, another tenant), the request is halved
+// down to `floor` slots before the call fails: a step then runs its samples in more, smaller batches -- same image.
+void free_pool(mi355pt_render* r) {
+    for (void* p : r->pool_allocs) (void)hipFree(p);
+    r->pool_allocs.clear();
+    DPaths& P = r->P;
+    P.cap = 0; P.id = nullptr; P.ray = nullptr; P.T = P.C = nullptr; P.hit = nullptr; P.sh = nullptr; P.queue[0] = P.queue[1] = nullptr;
+    P.squeue = nullptr; P.vqueue = nullptr; P.lhit = nullptr; P.prep = nullptr; P.vis = nullptr;
+}
+hipError_t alloc_pool(mi355pt_render* r, size_t cap) {
+    DPaths& P = r->P;
+    auto get = [&](void** p, size_t bytes) -> hipError_t { hipError_t e = hipMalloc(p, bytes); if (e == hipSuccess) r->pool_allocs.push_back(*p); return e; };
+    hipError_t e;
+#define PT_GET(ptr, bytes) if ((e = get((void**)&(ptr), (bytes))) != hipSuccess) return e
+    PT_GET(P.id, cap * 16); PT_GET(P.ray, cap * 32); PT_GET(P.T, cap * 16); PT_GET(P.C, cap * 16); PT_GET(P.hit, cap * 16);
+    PT_GET(P.sh, cap * 16 * P.shv); PT_GET(P.queue[0], cap * 4); PT_GET(P.queue[1], cap * 4); PT_GET(P.squeue, cap * 4); PT_GET(P.vqueue, cap * 8);
+    if (r->scene->model_lights) PT_GET(P.lhit, cap * 2 * sizeof(uint4));
+    if (r->prep_bounces) PT_GET(P.prep, cap * 4 * sizeof(float4));
+    PT_GET(P.vis, cap * 2);
+#undef PT_GET
+    P.cap = (uint32_t)cap;
+    return hipSuccess;
+}
+int ensure_pool(mi355pt_render* r, size_t want, size_t floor) {
+    want = std::min(std::max<size_t>(want, 64), r->pool_limit);
+    want = (want + 63) & ~(size_t)63;
+    floor = std::min(std::max<size_t>(floor, 64), want);
+    if (want <= r->P.cap) return MI355PT_OK;
+    if (r->P.cap >= floor && r->pool_oom_at && want >= r->pool_oom_at) return MI355PT_OK;      // this size failed before: keep what there is
+    HIP_TRY(hipStreamSynchronize(r->stream));
+    if (r->side) HIP_TRY(hipStreamSynchronize(r->side));
+    free_pool(r);
+    for (size_t cap = want;;) {
+        const hipError_t e = alloc_pool(r, cap);
+        if (e == hipSuccess) return MI355PT_OK;
+        free_pool(r);
+        (void)hipGetLastError();                                   // clear the sticky out-of-memory status
+        if (e != hipErrorOutOfMemory) return fail(MI355PT_ERR_HIP, std::string("path pool: ") + hipGetErrorString(e));
+        r->pool_oom_at = cap;
+        if (cap <= floor) return fail(MI355PT_ERR_HIP, "path pool: out of device memory for " + std::to_string(cap) + " path slots of " + std::to_string(90 + 16 * r->P.shv + (r->scene->model_lights ? 32 : 0) + (r->prep_bounces ? 64 : 0)) + " B (MI355PT_MAX_PATHS lowers the limit)");
+        cap = std::max(floor, ((cap / 2) + 63) & ~(size_t)63);
+    }
+}
 
 // One launch of the traversal kernel on `nwaves` persistent waves in workgroups of sh.wpb.
 template <int MODE>
@@ -2258,8 +2106,11 @@ int mi355pt_render_step(mi355pt_render* r, uint32_t spp) {
     PT_LOCK(r);
     HIP_TRY(hipSetDevice(r->device));
     const mi355pt_render_params& p = r->prm;
-    const size_t npix = r->own ? r->n_own : (size_t)p.width * p.height, cap = r->P.cap;
+    const size_t npix = r->own ? r->n_own : (size_t)p.width * p.height;
     if (npix == 0) return MI355PT_OK;
+    if (spp == 0) return MI355PT_OK;
+    if (int rc = ensure_pool(r, npix * (size_t)spp, std::min<size_t>(npix, 65536))) return rc;
+    const size_t cap = r->P.cap;
     const size_t ppc = std::min(npix, cap);
     const size_t spc = ppc == npix ? std::max<size_t>(1, cap / npix) : 1;
     const Params kprm{p.seed, p.width, p.height, p.max_bounces, p.rr_start, r->stack_entries, r->node_lanes, r->owner_lanes};
@@ -2333,7 +2184,8 @@ int mi355pt_trace_primary(mi355pt_render* r, uint32_t x0, uint32_t y0, uint32_t 
     PT_LOCK(r);
     HIP_TRY(hipSetDevice(r->device));
     const uint32_t rw = x1 - x0, rh = y1 - y0; const size_t n = (size_t)rw * rh;
-    if (n > r->P.cap) return fail(MI355PT_ERR_TOO_LARGE, "rectangle larger than the path pool");
+    if (n > r->pool_limit) return fail(MI355PT_ERR_TOO_LARGE, "rectangle larger than the path pool");
+    if (int rc = ensure_pool(r, n, n)) return rc;
     if (int rc = ensure_hook(r, n * 16)) return rc;
     int32_t *dn = (int32_t*)r->hook, *dm = dn + n, *df = dm + n; float* dt = (float*)(df + n);
     const mi355pt_render_params& p = r->prm;
@@ -2356,10 +2208,11 @@ int mi355pt_trace_primary(mi355pt_render* r, uint32_t x0, uint32_t y0, uint32_t 
 int mi355pt_trace_rays(mi355pt_render* r, const float* origins, const float* dirs, uint32_t count, int32_t* node, int32_t* mesh, int32_t* face, float* t) {
     if (!r || !origins || !dirs || !node || !mesh || !face || !t) return fail(MI355PT_ERR_INVALID, "null argument");
     if (count == 0) return MI355PT_OK;
-    if (count > r->P.cap) return fail(MI355PT_ERR_TOO_LARGE, "more rays than path slots");
+    if (count > r->pool_limit) return fail(MI355PT_ERR_TOO_LARGE, "more rays than path slots");
     PT_LOCK(r);
     HIP_TRY(hipSetDevice(r->device));
     const size_t n = count;
+    if (int rc = ensure_pool(r, n, n)) return rc;
     if (int rc = ensure_hook(r, n * 16)) return rc;
     int32_t *dn = (int32_t*)r->hook, *dm = dn + n, *df = dm + n; float* dt = (float*)(df + n);
     std::vector<float4> rays(2 * n);
@@ -2385,11 +2238,12 @@ int mi355pt_trace_rays(mi355pt_render* r, const float* origins, const float* dir
 int mi355pt_trace_visibility(mi355pt_render* r, const float* origins, const float* dirs, const float* tmax, int32_t light, uint32_t count, uint8_t* blocked) {
     if (!r || !origins || !dirs || !tmax || !blocked) return fail(MI355PT_ERR_INVALID, "null argument");
     if (count == 0) return MI355PT_OK;
-    if (count > r->P.cap) return fail(MI355PT_ERR_TOO_LARGE, "more rays than path slots");
+    if (count > r->pool_limit) return fail(MI355PT_ERR_TOO_LARGE, "more rays than path slots");
     if (light < 0 || light >= r->scene->d.num_lights) return fail(MI355PT_ERR_INVALID, "light index out of range");
     PT_LOCK(r);
     HIP_TRY(hipSetDevice(r->device));
     const size_t n = count;
+    if (int rc = ensure_pool(r, n, n)) return rc;
     // one visibility item per ray, shaped like the ones k_shade queues for a light sample (item = slot * 2 + 0)
     const size_t shv = r->P.shv;
     std::vector<float4> sh(shv * n, make_float4(0.0f, 0.0f, 0.0f, 0.0f));
@@ -2424,11 +2278,12 @@ int mi355pt_trace_visibility(mi355pt_render* r, const float* origins, const floa
 int mi355pt_sample_radiance(mi355pt_render* r, const uint32_t* pixel, const uint32_t* sample, uint32_t count, float* linear_rgb, float* mapped_rgb) {
     if (!r || !pixel || !sample) return fail(MI355PT_ERR_INVALID, "null argument");
     if (count == 0) return MI355PT_OK;
-    if (count > r->P.cap) return fail(MI355PT_ERR_TOO_LARGE, "more samples than path slots");
+    if (count > r->pool_limit) return fail(MI355PT_ERR_TOO_LARGE, "more samples than path slots");
     const size_t npix = (size_t)r->prm.width * r->prm.height;
     for (uint32_t i = 0; i < count; i++) if (pixel[i] >= npix) return fail(MI355PT_ERR_INVALID, "pixel index out of range");
     PT_LOCK(r);
     HIP_TRY(hipSetDevice(r->device));
+    if (int rc = ensure_pool(r, count, count)) return rc;
     if (int rc = ensure_hook(r, (size_t)count * 32)) return rc;
     uint32_t *dp = (uint32_t*)r->hook, *ds = dp + count; float *dl = (float*)(ds + count), *dm = dl + 3 * (size_t)count;
     HIP_TRY(hipStreamSynchronize(r->stream));
@@ -2455,6 +2310,10 @@ int mi355pt_trace_rays_static(mi355pt_scene* scene, const float* d_origins, cons
     if (count == 0) return MI355PT_OK;
     if (count > kStaticMaxRays) return fail(MI355PT_ERR_TOO_LARGE, "more rays than MI355PT_STATIC_MAX_RAYS (the static scratch array holds that many)");
     if (!scene->static_scratch) return fail(MI355PT_ERR_HIP, "static scratch address not set up");
+    { std::lock_guard<std::mutex> g(scene->life); if (scene->doomed) return fail(MI355PT_ERR_INVALID, "the scene has been destroyed"); }
+    // the calling thread's current device is put back on every way out (hipSetDevice allocates nothing)
+    struct DeviceGuard { int prev = -1; ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); } } guard;
+    if (hipGetDevice(&guard.prev) != hipSuccess) guard.prev = -1;
     HIP_TRY(hipSetDevice(scene->device));
     hipStream_t st = (hipStream_t)stream;
     unsigned char* base = scene->static_scratch;            // never the array's name: that is a host-side stand-in
@@ -2465,8 +2324,10 @@ int mi355pt_trace_rays_static(mi355pt_scene* scene, const float* d_origins, cons
     P.spill = (uint32_t*)(base + kStaticSpillOff);
     // the array keeps the last call's contents: the work counter and the guard word must start at zero
     HIP_TRY(hipMemsetAsync(base + kStaticCtrOff, 0, 256, st));
-    Params prm{0u, 1u, 1u, 1u, 0u, scene->static_entries, kNodeLanes, 64u, 0u, 0u};
-    prm.setup_min = 32u;                    // the renderer's default (mi355pt_render)
+    // the traversal knobs a renderer reads from the environment reach this path too (taken once, at scene creation): the
+    // exhaustive walk of MI355PT_NO_CULL is the "exact" switch here as there
+    Params prm{0u, 1u, 1u, 1u, 0u, scene->static_entries, scene->static_node_lanes, 64u, 0u, 0u, scene->static_no_cull};
+    prm.setup_min = scene->static_setup_min;
     const int g = (int)std::max<size_t>(1, std::min<size_t>(((size_t)count + kBlock - 1) / kBlock, 2048));
     const int ge = (int)std::max<size_t>(1, std::min<size_t>(((size_t)count + 63) / 64, kStaticWaves));
     hipLaunchKernelGGL(k_static_in, dim3(g), dim3(kBlock), 0, st, d_origins, d_dirs, count, P.ray);
@@ -2476,6 +2337,18 @@ int mi355pt_trace_rays_static(mi355pt_scene* scene, const float* d_origins, cons
     return MI355PT_OK;
 }
 
+int mi355pt_render_get_params(mi355pt_render* r, mi355pt_render_params* params) {
+    if (!r || !params) return fail(MI355PT_ERR_INVALID, "null argument");
+    *params = r->prm;
+    return MI355PT_OK;
+}
+int mi355pt_render_stats_sized(mi355pt_render* r, void* stats, uint32_t struct_bytes) {
+    if (!r || !stats) return fail(MI355PT_ERR_INVALID, "null argument");
+    mi355pt_stats full;
+    if (int rc = mi355pt_render_stats(r, &full)) return rc;
+    memcpy(stats, &full, std::min<size_t>(struct_bytes, sizeof(full)));
+    return MI355PT_OK;
+}
 int mi355pt_render_stats(mi355pt_render* r, mi355pt_stats* st) {
     if (!r || !st) return fail(MI355PT_ERR_INVALID, "null argument");
     PT_LOCK(r);
@@ -2487,7 +2360,7 @@ int mi355pt_render_stats(mi355pt_render* r, mi355pt_stats* st) {
     st->shadow_node_visits = h[5]; st->shadow_tri_tests = h[6]; st->max_nodes_per_ray = 0;
     st->extend_ms = r->ms[0]; st->shade_ms = r->ms[1]; st->connect_ms = r->ms[2]; st->other_ms = r->ms[3];
     st->extend_launches = r->extend_launches;
-    st->shaded_vertices = h[16]; st->texture_taps = h[17];
+    st->shaded_vertices = h[16]; st->texture_taps = h[17]; st->shadow_rays_traversed = h[19];
     return MI355PT_OK;
 }
 int mi355pt_render_reset_stats(mi355pt_render* r) {

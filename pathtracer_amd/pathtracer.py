@@ -8,6 +8,7 @@ workers are the HIP kernels behind libmi355pt.so.  There is no CPU fallback: eve
 method raises if the HIP library is missing or no gfx950 device is present.
 """
 import ctypes as C
+import os
 import threading
 
 import numpy as np
@@ -25,6 +26,25 @@ class DeviceScene:
         h = C.c_void_p()
         capi.check(self.lib, self.lib.mi355pt_scene_create(C.byref(self.desc), device, C.byref(h)), "mi355pt_scene_create")
         self.h = h
+
+    @classmethod
+    def load(cls, path, device=0):
+        """mi355pt_scene_load: a scene another process flattened and saved (one host build for N ranks)."""
+        self = cls.__new__(cls)
+        self.lib = capi.load_library()
+        self.desc, self._keep, self.device = None, None, device
+        h = C.c_void_p()
+        capi.check(self.lib, self.lib.mi355pt_scene_load(os.fsencode(path), device, C.byref(h)), "mi355pt_scene_load")
+        self.h = h
+        return self
+
+    @staticmethod
+    def save(scene, path, with_trees=False):
+        """mi355pt_scene_save: flatten `scene` on the host (no GPU needed) and write it to `path`."""
+        lib = capi.load_library()
+        desc, keep = scene.to_desc()
+        capi.check(lib, lib.mi355pt_scene_save(C.byref(desc), os.fsencode(path), capi.SAVE_TREES if with_trees else 0), "mi355pt_scene_save")
+        del keep
 
     def get_bvh(self, mesh=0):
         nn, nf = capi.u32(0), capi.u32(0)
@@ -203,6 +223,69 @@ class PathTracer:
     def __del__(self):
         try:
             self.close_render()
+        except Exception:
+            pass
+
+
+class PathTracerGroup:
+    """mi355pt_group: one process driving several GPUs (or several shards of one GPU) -- one host build, one upload per
+    device, the work split by sample index or by interleaved image tile, the read-out one RCCL reduce (include/mi355pt.h)."""
+
+    def __init__(self, scene, devices=(0,), split="sample", seed=0x5EED, max_bounces=30, rr_start=3, force_rccl=False):
+        self.lib = capi.load_library()
+        self.scene = scene
+        self.devices = [int(d) for d in devices]
+        self.split = {"sample": capi.SPLIT_SAMPLE, "tile": capi.SPLIT_TILE}[split]
+        self._cfg = dict(seed=seed, max_bounces=max_bounces, rr_start=rr_start)
+        self.flags = capi.GROUP_FORCE_RCCL if force_rccl else 0
+        self.h = None
+        self.width = self.height = self.size = 0
+
+    def Init(self, width, height):
+        self.close()
+        self.width, self.height, self.size = int(width), int(height), int(width) * int(height)
+        desc, keep = self.scene.to_desc()
+        prm = capi.make_params(self.width, self.height, **self._cfg)
+        devs = (capi.i32 * len(self.devices))(*self.devices)
+        h = C.c_void_p()
+        capi.check(self.lib, self.lib.mi355pt_group_create(C.byref(desc), devs, len(self.devices), C.byref(prm), self.split, self.flags, C.byref(h)),
+                   "mi355pt_group_create")
+        del keep                                              # the library copied everything it needs
+        self.h = h
+
+    def step(self, spp=1):
+        capi.check(self.lib, self.lib.mi355pt_group_step(self.h, spp), "mi355pt_group_step")
+
+    def sync(self):
+        capi.check(self.lib, self.lib.mi355pt_group_sync(self.h), "mi355pt_group_sync")
+
+    def GetPixels(self):
+        out = np.zeros((self.height, self.width, 3), dtype=np.uint8)
+        capi.check(self.lib, self.lib.mi355pt_group_read_rgb8(self.h, out.ctypes.data), "group_read_rgb8")
+        return out
+
+    def read_accum(self):
+        mean = np.zeros((self.size, 3), dtype=np.float32)
+        cnt = np.zeros(self.size, dtype=np.uint32)
+        capi.check(self.lib, self.lib.mi355pt_group_read_accum(self.h, mean.ctypes.data, cnt.ctypes.data), "group_read_accum")
+        return mean, cnt
+
+    def stats(self):
+        st = capi.Stats()
+        capi.check(self.lib, self.lib.mi355pt_group_stats(self.h, C.byref(st)), "group_stats")
+        return {k: (list(getattr(st, k)) if k == "debug" else getattr(st, k)) for k, _ in capi.Stats._fields_}
+
+    def readout_ms(self):
+        return float(self.lib.mi355pt_group_readout_ms(self.h))
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.mi355pt_group_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
         except Exception:
             pass
 

@@ -386,6 +386,8 @@ class Scene:
         for m in self.materials:
             mat_index(m)
         cnodes = (capi.Node * len(nodes))()
+        node_index = {id(n): i for i, n in enumerate(nodes)}
+        light_index = {}
         for i, n in enumerate(nodes):
             cn = cnodes[i]
             cn.tm[:] = n.tm.tolist(); cn.itm[:] = n.itm.tolist(); cn.pos[:] = n.pos.tolist()
@@ -399,10 +401,14 @@ class Scene:
                     models.append((n.obj, len(meshes)))
                     meshes.extend(n.obj.meshes)
             cn.material = mat_index(n.GetMaterial())
+            # Every node that carries the component emits (render.h:137, disneyMaterial.h:194); the component's `parent` --
+            # the last node SetLight reached (model.h:390) -- is the one it is sampled on.  lightList order = first reference.
             cn.light = -1
-            if n.light is not None and n.light.parent is n:
-                cn.light = len(lights)
-                lights.append((n.light, i))
+            if n.light is not None and id(n.light.parent) in node_index:
+                if id(n.light) not in light_index:
+                    light_index[id(n.light)] = len(lights)
+                    lights.append((n.light, node_index[id(n.light.parent)]))
+                cn.light = light_index[id(n.light)]
 
         cmats = (capi.Material * max(1, len(mats)))()
         for i, m in enumerate(mats):
