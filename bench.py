@@ -7,11 +7,14 @@ Disney rough material + one rectangular area light, primary + secondary rays, 30
 One "step" = one batch of --spp-per-step (default 16) samples per pixel of the whole frame through the full hot path
 (init -> {extend, shade, connect} x bounces -> resolve) with the scene resident in HBM.
 
-N GPUs: one process per GPU (torch.distributed, backend nccl == RCCL); the scene is replicated and
-the work is split with no data-path collective (weak scaling: per-GPU work fixed) either by sample
-index (default: GPU g renders samples g, g+N, ... of every pixel) or by image tile (--split tile:
-GPU g renders N samples per step of the 64x64 tiles k with k % N == g).  The per-GPU running means
-are combined by ONE RCCL reduce at the end of the timed region.
+N GPUs: one process per GPU (torchrun; torch.distributed with the gloo backend is the control plane only: rendezvous, barriers,
+the max-over-ranks clock).  Rank 0 builds the scene and its BVH ONCE and saves the flattened arrays (mi355pt_scene_save); every
+rank maps that file and uploads it (mi355pt_scene_load).  The work is split with no data-path collective -- weak scaling
+(default: per-GPU work fixed) or strong (--scaling strong: the step's samples are divided among the GPUs) -- either by sample
+index (default: GPU g renders samples g, g+N, ... of every pixel) or by image tile (--split tile: GPU g renders the 64x64 tiles
+k with k % N == g).  The per-GPU running means are combined by ONE RCCL reduce inside the library (mi355pt_comm_* +
+mi355pt_render_reduce, librccl of the ROCm the library is linked against) at the end of the timed region; rank 0 checks the
+combined sample counts.  torch never touches the GPU here: the process holds one HIP runtime.
 
 Prints ONE JSON line (rank 0).
 """
@@ -96,6 +99,11 @@ def main():
     ap.add_argument("--split", choices=["sample", "tile"], default="sample")
     ap.add_argument("--spp-per-step", type=int, default=16,
                     help="samples per pixel in one step = one batch through the hot path (the late bounces' fixed cost is paid once per batch)")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="weak: every GPU renders --spp-per-step samples per step (of every pixel / of its tiles x N); strong: the step's --spp-per-step samples are divided among the GPUs")
+    ap.add_argument("--total-spp", type=int, default=0, help="strong scaling: total samples per pixel of the job (sets --steps = total / spp-per-step), e.g. C3's 1024")
+    ap.add_argument("--readout", choices=["library", "gloo"], default="library",
+                    help="N > 1: library = RCCL reduce inside libmi355pt.so (falls back to gloo if the communicator cannot be created); gloo = host-staged reduce")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -105,20 +113,28 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus and world > 1:
         log(f"warning: WORLD_SIZE={world} but --gpus {args.gpus}")
+    import resource
     import torch
     dist = None
-    if world > 1 or os.environ.get("BENCH_FORCE_DIST"):     # BENCH_FORCE_DIST: rehearse the N>1 read-out path on one GPU
+    force = bool(os.environ.get("BENCH_FORCE_DIST"))         # rehearse the N > 1 paths (scene file, communicator, reduce) on one GPU
+    if world > 1 or force:
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if force and world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
+            os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
+            log("rehearsing the distributed paths with world size 1")
+        dist.init_process_group("gloo")                     # control plane only; the data plane is RCCL inside the library
     device = local_rank if world > 1 else 0
-    if dist is not None and world == 1:
-        log("rehearsing the distributed read-out with world size 1")
 
-    from pathtracer_amd import PathTracer, capi, distributed
+    from pathtracer_amd import DeviceScene, PathTracer, capi, distributed
     lib = capi.load_library()
     if lib.mi355pt_device_count() < 1:
         raise SystemExit("bench.py needs a gfx950 device; there is no CPU fallback")
+    if args.scaling == "strong":
+        if args.total_spp:
+            args.steps = max(1, args.total_spp // args.spp_per_step)
+        if args.split == "sample" and args.spp_per_step % world:
+            raise SystemExit("--scaling strong with the sample split needs --spp-per-step divisible by the number of GPUs")
 
     t0 = time.perf_counter()
     # building a 100 M-triangle scene (C5), its counting-build step and its CPU leg take minutes in silence: a line on stderr
@@ -129,35 +145,113 @@ def main():
 
     def heartbeat():
         while not building.wait(30.0):
-            log(f"[bench] {phase[0]}, {time.perf_counter() - t0:.0f} s")
+            log(f"[bench] rank {rank}: {phase[0]}, {time.perf_counter() - t0:.0f} s")
     threading.Thread(target=heartbeat, daemon=True).start()
-    scene, workload = build_scene(args)
+
+    def peak_rss_gb():
+        return resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 1048576.0
+
+    # ---- the scene: ONE host build.  One rank: built and uploaded in place.  N ranks: rank 0 flattens it into a file that every
+    # rank maps (the file's pages are shared; a loading rank never holds a private copy of the scene).
+    scene, workload, host = None, None, {}
+    if dist is None:
+        scene, workload = build_scene(args)
+        dscene = DeviceScene(scene, device)
+        tris = int(dscene.desc.meshes[0].num_faces) if dscene.desc.num_meshes else 0
+        host = {"host_build_s": time.perf_counter() - t0, "host_peak_rss_gb": peak_rss_gb(), "builds": 1}
+    else:
+        sdir = os.environ.get("MI355PT_SCENE_DIR") or ("/dev/shm" if os.path.isdir("/dev/shm") else "/tmp")
+        spath = os.path.join(sdir, f"mi355pt_bench_{os.environ.get('MASTER_PORT', '0')}.scene")
+        tris = 0
+        if rank == 0:
+            scene, workload = build_scene(args)
+            for n in scene.rootNode.children:
+                if n.obj is not None and getattr(n.obj, "meshes", None):
+                    tris = max(tris, int(n.obj.meshes[0].faces.shape[0]))
+            DeviceScene.save(scene, spath)
+            host = {"host_build_s": time.perf_counter() - t0, "host_peak_rss_gb": peak_rss_gb(), "builds": 1,
+                    "scene_file_gb": os.path.getsize(spath) / 1e9}
+            scene = None                                       # the Python arrays are not needed any more (N > 1 runs no CPU leg)
+        dist.barrier()
+        phase[0] = "loading the scene file"
+        tl = time.perf_counter()
+        dscene = DeviceScene.load(spath, device)
+        load_s = time.perf_counter() - tl
+        v = torch.tensor([load_s, peak_rss_gb() if rank else 0.0], dtype=torch.float64)
+        dist.all_reduce(v, op=dist.ReduceOp.MAX)
+        host.update({"scene_load_s_max": float(v[0]), "loader_peak_rss_gb_max": float(v[1])})
+        dist.barrier()
+        if rank == 0:
+            os.remove(spath)
+    strong = args.scaling == "strong"
     if args.split == "tile":
         ts, toff, tstride = distributed.rank_tile_split(rank, world, 64)
-        pt = PathTracer(scene, device=device, seed=args.seed, tile_size=ts, tile_offset=toff, tile_stride=tstride)
-        spp_step = world * args.spp_per_step        # a rank owns 1/N of the pixels: N samples of each keep the per-GPU work fixed
+        pt = PathTracer(dscene, device=device, seed=args.seed, tile_size=ts, tile_offset=toff, tile_stride=tstride)
+        # a rank owns 1/N of the pixels: weak = N samples of each keep the per-GPU work fixed; strong = the step's samples of its tiles
+        spp_step = args.spp_per_step if strong else world * args.spp_per_step
     else:
         off, stride = distributed.rank_sample_split(rank, world)
-        pt = PathTracer(scene, device=device, seed=args.seed, sample_offset=off, sample_stride=stride)
-        spp_step = args.spp_per_step
+        pt = PathTracer(dscene, device=device, seed=args.seed, sample_offset=off, sample_stride=stride)
+        spp_step = args.spp_per_step // world if strong else args.spp_per_step
     pt.Init(args.width, args.height)
     phase[0] = "running"
     if rank == 0:
-        log(f"scene + BVH + upload: {time.perf_counter() - t0:.1f} s")
+        log(f"scene + BVH + upload: {time.perf_counter() - t0:.1f} s  {host}")
+
+    # ---- the read-out of N > 1: a communicator inside the library (RCCL); every rank must have one, or all take the gloo path
+    comm, readout = None, None
+    if dist is not None:
+        readout = "gloo"
+        if args.readout == "library":
+            uid = (C.c_uint8 * capi.COMM_ID_BYTES)()
+            ok = 1
+            if rank == 0 and lib.mi355pt_comm_unique_id(uid) != 0:
+                log("mi355pt_comm_unique_id failed:", lib.mi355pt_last_error().decode()); ok = 0
+            t = torch.tensor(list(bytes(uid)) + [ok], dtype=torch.int32)
+            dist.broadcast(t, 0)
+            ok = int(t[-1])
+            if ok:
+                uid = (C.c_uint8 * capi.COMM_ID_BYTES)(*[int(x) for x in t[:-1]])
+                h = C.c_void_p()
+                if lib.mi355pt_comm_create(uid, rank, world, device, C.byref(h)) != 0:
+                    log(f"rank {rank}: mi355pt_comm_create failed:", lib.mi355pt_last_error().decode()); ok = 0
+                else:
+                    comm = h
+            t = torch.tensor([ok], dtype=torch.int32)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            if int(t[0]):
+                readout = "rccl-in-library"
+            elif rank == 0:
+                log("falling back to the host-staged gloo reduce")
+
+    def read_out():
+        """(mean, count, device ms) of the combined image on rank 0; (None, None, ms) elsewhere."""
+        split = capi.SPLIT_TILE if args.split == "tile" else capi.SPLIT_SAMPLE
+        if readout == "rccl-in-library":
+            mean = np.zeros((pt.size, 3), dtype=np.float32) if rank == 0 else None
+            cnt = np.zeros(pt.size, dtype=np.uint32) if rank == 0 else None
+            ms = C.c_double(0)
+            capi.check(lib, lib.mi355pt_render_reduce(pt.h, comm, 0, split, mean.ctypes.data if rank == 0 else None,
+                                                      cnt.ctypes.data if rank == 0 else None, None, C.byref(ms)), "mi355pt_render_reduce")
+            return mean, cnt, ms.value
+        m, c = pt.read_accum()
+        res = distributed.combine_running_means(torch.from_numpy(m), torch.from_numpy(c.astype(np.int32)), dist, 0)
+        if res is None:
+            return None, None, 0.0
+        return res[0].numpy(), res[1].numpy().astype(np.uint32), 0.0
 
     def barrier():
         if dist is not None:
             dist.barrier()
         pt.sync()
-        torch.cuda.synchronize()
+        if torch.cuda.is_initialized():      # (it is not: this process runs ONE HIP runtime, the library's; pt.sync() is the device sync)
+            torch.cuda.synchronize()
 
     for _ in range(args.warmup):
         pt.step(spp_step)
     pt.sync()
-    if dist is not None and args.warmup > 0:     # the read-out is part of a step's work: warm it up too (RCCL communicator, torch kernels)
-        mean_t, cnt_t = distributed.accum_tensors(pt)
-        distributed.combine_running_means(mean_t, cnt_t, dist, 0)
-        torch.cuda.synchronize()
+    if dist is not None and args.warmup > 0:     # the read-out is part of the job: warm it up too (RCCL channels, buffers)
+        read_out()
     pt.reset_stats()
     pt.set_profiling(events=1, count_work=False)        # HIP events around every launch of the dominant kernel, on its stream
     npix = args.width * args.height
@@ -166,15 +260,26 @@ def main():
     for _ in range(args.steps):
         pt.step(spp_step)
     pt.sync()
-    if dist is not None:            # read-out: ONE RCCL reduce of (n*mean, n) per pixel, straight from the accumulators in HBM
-        mean_t, cnt_t = distributed.accum_tensors(pt)
-        combined = distributed.combine_running_means(mean_t, cnt_t, dist, 0)
+    readout_ms, combined = None, None
+    if dist is not None:            # read-out: ONE reduce of 4 floats per pixel, straight from the accumulators in HBM
+        tr = time.perf_counter()
+        cmean, ccnt, dev_ms = read_out()
+        readout_ms = {"wall": (time.perf_counter() - tr) * 1e3, "device": dev_ms}
+        combined = (cmean, ccnt)
     barrier()
     dt = time.perf_counter() - t0
     st = pt.stats()
     rays = st["closest_rays"] + st["shadow_rays"]
     if dist is not None:
-        v = torch.tensor([dt, float(rays), float(st["samples"])], dtype=torch.float64).cuda()
+        if rank == 0:
+            # the image the job produced: every pixel must hold every sample of every rank, and finite tone-mapped values
+            want = (args.warmup + args.steps) * (spp_step * world if args.split == "sample" else spp_step)
+            cmean, ccnt = combined
+            if not (ccnt == want).all():
+                raise SystemExit(f"combined sample counts are wrong: expected {want} everywhere, got min {int(ccnt.min())} max {int(ccnt.max())}")
+            if not (np.isfinite(cmean).all() and cmean.min() >= 0.0 and cmean.max() <= 1.0 and cmean.max() > 0.0):
+                raise SystemExit("the combined image is not a finite tone-mapped image in [0, 1]")
+        v = torch.tensor([dt, float(rays), float(st["samples"])], dtype=torch.float64)
         mx = v.clone(); dist.all_reduce(mx, op=dist.ReduceOp.MAX)
         sm = v.clone(); dist.all_reduce(sm, op=dist.ReduceOp.SUM)
         dt, rays_total, samples_total = float(mx[0]), float(sm[1]), float(sm[2])
@@ -186,15 +291,25 @@ def main():
         out = {
             "metric": "Mrays/s", "value": rays_total / dt / 1e6, "unit": "Mrays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": workload, "triangles": int(pt.dscene.desc.meshes[0].num_faces) if pt.dscene.desc.num_meshes else 0,
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": workload, "triangles": tris,
                        "resolution": [args.width, args.height], "spp_per_step": args.spp_per_step, "max_bounces": 30,
-                       "split": ("sample index g, g+N, ... per GPU" if args.split == "sample" else "64x64 image tiles k % N == g, N spp per step")
-                                + "; one RCCL reduce at the end"},
+                       "spp_per_step_per_gpu": spp_step,
+                       "split": ("sample index g, g+N, ... per GPU" if args.split == "sample" else "64x64 image tiles k % N == g")
+                                + "; one RCCL reduce at the end",
+                       # the distance cull of DESIGN.md section 3 item 8 (MI355PT_NO_CULL=1: the reference's exhaustive walk)
+                       "cull": "none" if os.environ.get("MI355PT_NO_CULL") else ("plain" if os.environ.get("MI355PT_CULL_PLAIN") else "margin")},
             "samples_per_pixel_per_s": samples_total / npix / dt,
-            "ms_per_sample": dt / args.steps / args.spp_per_step * 1e3,
+            "ms_per_sample": dt / max(samples_total / npix, 1e-9) * 1e3,
             "rays_per_sample": rays_total / max(samples_total, 1.0),
+            # LightVisTest calls that entered a visibility kernel; the rest of shadow_rays were decided in k_shade (still one call each)
+            "shadow_rays_traversed_share": st["shadow_rays_traversed"] / max(st["shadow_rays"], 1),
+            "host": host,
         }
+        if dist is not None:
+            out["readout"] = readout
+            out["readout_ms"] = readout_ms
+            out["combined_counts_checked"] = True
     # ---- roofline of the workload's dominant kernel: algorithmic bytes / measured launch time (HIP events on its stream)
     if rank == 0 and not args.no_roofline:
         ext_ms, launches = st["extend_ms"], st["extend_launches"]
@@ -265,16 +380,29 @@ def main():
                  "bytes_per_vertex": shade_bytes / max(verts, 1), "vertices": int(verts), "texture_lookups_per_vertex": taps / max(verts, 1),
                  "ms_exclusive": xs["shade_ms"],
                  "note": "instruction-bound: about 4 000 VALU wave-instructions per vertex (DESIGN.md section 3); the HBM fraction is reported because the contract asks for it"}
+        # visibility stage (k_trace<any> + the MIS combination): the same record formula with the visibility traversal's own node and
+        # triangle counts, over the LightVisTest calls that reached the kernel, in the exclusive step's time for the stage
+        vis_rays = cs["shadow_rays_traversed"]
+        vn, vt = cs["shadow_node_visits"] / max(vis_rays, 1), cs["shadow_tri_tests"] / max(vis_rays, 1)
+        vis_bytes_per_ray = NODE_BYTES * vn + TRI_BYTES * vt + QUEUE_BYTES
+        vis_ach = xs["shadow_rays_traversed"] * vis_bytes_per_ray / (xs["connect_ms"] * 1e-3) / 1e9 if xs["connect_ms"] > 0 else 0.0
+        out["roofline_visibility"] = {"bound": "hbm", "kernel": "k_trace<any> + connect (visibility stage)", "achieved": vis_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                      "frac": vis_ach / HBM_PEAK_GBS, "traffic": tj.get("k_trace_any_bytes_per_launch") if tj else None, "traffic_source": traffic_source,
+                                      "bytes_per_ray": vis_bytes_per_ray, "n_node_per_ray": vn, "n_tri_per_ray": vt,
+                                      "rays_traversed": int(xs["shadow_rays_traversed"]), "light_vis_tests": int(xs["shadow_rays"]), "ms_exclusive": xs["connect_ms"]}
         # the workload's dominant kernel goes to `roofline`, the other is kept beside it
         if xs["shade_ms"] > xs["extend_ms"]:
             out["roofline"], out["roofline_extend"] = shade, trace
         else:
             out["roofline"], out["roofline_shade"] = trace, shade
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and dist is None and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(scene, pt, args)
     if rank == 0:
         print(json.dumps(out), flush=True)
+    building.set()
     pt.close_render()
+    if comm is not None:
+        lib.mi355pt_comm_destroy(comm)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -383,6 +383,10 @@ typedef struct mi355pt_group mi355pt_group;
 int mi355pt_group_create(const mi355pt_scene_desc* desc, const int32_t* devices, uint32_t num_shards, const mi355pt_render_params* params,
                          int32_t split, uint32_t flags, mi355pt_group** out);
 void mi355pt_group_destroy(mi355pt_group* group);
+/* PathTracer::Init on a live group (src/pathtracer.cpp:13-21; RayTracer::Restart re-inits with the scene unchanged,
+ * src/raytracer.cpp:377-382): fresh accumulators of width x height on every shard; the uploaded scenes and the
+ * communicators are kept -- no host build, no upload. */
+int mi355pt_group_reset(mi355pt_group* group, uint32_t width, uint32_t height);
 int mi355pt_group_step(mi355pt_group* group, uint32_t spp);
 int mi355pt_group_sync(mi355pt_group* group);
 int mi355pt_group_read_rgb8(mi355pt_group* group, uint8_t* rgb);

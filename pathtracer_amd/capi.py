@@ -108,7 +108,7 @@ SYMBOLS = [
     "mi355pt_trace_rays_static", "mi355pt_trace_visibility",
     "mi355pt_abi_version", "mi355pt_scene_create_multi", "mi355pt_scene_save", "mi355pt_scene_load",
     "mi355pt_render_stats_sized", "mi355pt_render_get_params",
-    "mi355pt_group_create", "mi355pt_group_destroy", "mi355pt_group_step", "mi355pt_group_sync", "mi355pt_group_read_rgb8",
+    "mi355pt_group_create", "mi355pt_group_destroy", "mi355pt_group_reset", "mi355pt_group_step", "mi355pt_group_sync", "mi355pt_group_read_rgb8",
     "mi355pt_group_read_accum", "mi355pt_group_stats", "mi355pt_group_size", "mi355pt_group_render", "mi355pt_group_readout_ms",
     "mi355pt_comm_unique_id", "mi355pt_comm_create", "mi355pt_comm_destroy", "mi355pt_render_reduce",
 ]
@@ -172,6 +172,7 @@ def load_library(path=None):
     lib.mi355pt_group_create.argtypes = [C.POINTER(SceneDesc), C.POINTER(i32), u32, C.POINTER(RenderParams), i32, u32, C.POINTER(vp)]
     lib.mi355pt_group_destroy.argtypes = [vp]
     lib.mi355pt_group_destroy.restype = None
+    lib.mi355pt_group_reset.argtypes = [vp, u32, u32]
     lib.mi355pt_group_step.argtypes = [vp, u32]
     lib.mi355pt_group_sync.argtypes = [vp]
     lib.mi355pt_group_read_rgb8.argtypes = [vp, C.c_void_p]

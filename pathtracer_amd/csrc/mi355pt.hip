@@ -70,6 +70,7 @@ struct DPaths {
     uint32_t *spill_any;  // the same for k_trace<ANY>, which may run beside k_trace<closest> of the next bounce
     unsigned long long *stat;   // [0] closest rays [1] shadow rays [2] samples [3,4] extend node visits / tri tests [5,6] visibility ditto [7] guard
                                 // [8..15] counting builds' diagnostics [16] vertices shaded [17] bilinear texture lookups [18] rays bounce 0's pre-pass finished in the current run
+                                // [19] visibility items that entered a visibility kernel (k_trace<1> / k_vis_connect)
 };
 struct Params { uint32_t seed, width, height, max_bounces, rr_start, stack_entries, node_lanes, owner_lanes, gen, use_prep, no_cull, ntop, setup_min; };
 
@@ -1310,9 +1311,10 @@ __global__ void __launch_bounds__(kBlock) k_gather(DPaths P, uint32_t n, float* 
 }
 __global__ void k_stats(DPaths P, uint32_t n0, uint32_t max_bounces) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
-        unsigned long long c = n0;
+        unsigned long long c = n0, v = 0;
         for (uint32_t b = 1; b < max_bounces; b++) c += P.counts[b];
-        P.stat[0] += c; P.stat[2] += n0;
+        for (uint32_t b = 0; b < max_bounces; b++) v += P.svcounts[b] >> 32;      // visibility items k_shade queued (none when it resolved them itself)
+        P.stat[0] += c; P.stat[2] += n0; P.stat[19] += v;
     }
 }
 

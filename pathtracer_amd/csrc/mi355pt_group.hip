@@ -136,6 +136,7 @@ struct mi355pt_group {
     struct Dev { int device = 0; hipStream_t stream = nullptr; ncclComm_t comm = nullptr; int first_shard = -1; };
     std::vector<Shard> shards; std::vector<Dev> devs;
     int split = MI355PT_SPLIT_SAMPLE; bool use_rccl = false;
+    mi355pt_render_params tmpl{};                     // the caller's parameters; every shard's are derived from them
     size_t npix = 0; uint32_t width = 0, height = 0;
     Combined out; bool combined_valid = false;
     hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -188,6 +189,38 @@ int combine_group(mi355pt_group* g) {
     return MI355PT_OK;
 }
 
+// the per-image part of a group: one renderer per shard, the packed read-out buffers, the combined image
+void drop_renderers(mi355pt_group* g) {
+    for (auto& s : g->shards) { if (s.render) mi355pt_render_destroy(s.render); s.render = nullptr; }
+    for (auto& s : g->shards) if (s.pack) { (void)hipSetDevice(s.device); (void)hipFree(s.pack); s.pack = nullptr; }
+    if (!g->devs.empty()) (void)hipSetDevice(g->devs[0].device);
+    g->out.release();
+    g->combined_valid = false;
+}
+int make_renderers(mi355pt_group* g, const mi355pt_render_params* params) {
+    const uint32_t num_shards = (uint32_t)g->shards.size();
+    const int split = g->split;
+    g->tmpl = *params; g->width = params->width; g->height = params->height; g->npix = (size_t)params->width * params->height;
+    // a shard's share composes with the caller's own split (this process may itself be one of several)
+    for (uint32_t i = 0; i < num_shards; i++) {
+        mi355pt_render_params p = *params;
+        p.device = g->shards[i].device;
+        if (split == MI355PT_SPLIT_SAMPLE) { p.sample_offset = params->sample_offset + i * params->sample_stride; p.sample_stride = params->sample_stride * num_shards; }
+        else if (num_shards > 1 || (params->tile_size > 0 && params->tile_stride > 1)) {
+            const uint32_t ts = params->tile_size ? params->tile_size : 64u, st = params->tile_size && params->tile_stride ? params->tile_stride : 1u;
+            p.tile_size = ts; p.tile_offset = (params->tile_size ? params->tile_offset : 0u) + i * st; p.tile_stride = st * num_shards;
+        }
+        if (int rc = mi355pt_render_create(g->shards[i].scene, &p, &g->shards[i].render)) return rc;
+    }
+    // read-out: per shard a packed buffer, the combined image on the first device (a single shard without RCCL needs neither)
+    if (num_shards > 1 || g->use_rccl) {
+        for (auto& s : g->shards) { HIP_TRY(hipSetDevice(s.device)); HIP_TRY(hipMalloc((void**)&s.pack, g->npix * sizeof(float4))); }
+        HIP_TRY(hipSetDevice(g->devs[0].device));
+        if (int rc = g->out.alloc(g->npix)) return rc;
+    }
+    return MI355PT_OK;
+}
+
 // runs fn(shard index) on one host thread per shard (the early-stop poll of render_step blocks its caller until the GPU is two
 // bounces from the end of the step: N devices need N callers); returns the first failure with its message
 template <typename F>
@@ -231,25 +264,9 @@ int mi355pt_group_create(const mi355pt_scene_desc* desc, const int32_t* devices,
     std::vector<mi355pt_scene*> scenes(devlist.size(), nullptr);
     if (int rc = mi355pt_scene_create_multi(desc, devlist.data(), (uint32_t)devlist.size(), scenes.data())) return cleanup(rc);
     for (auto& s : g->shards) s.scene = scenes[s.dev_slot];
-    // ---- one renderer per shard; a shard's share composes with the caller's own split (this process may itself be one of several)
-    for (uint32_t i = 0; i < num_shards; i++) {
-        mi355pt_render_params p = *params;
-        p.device = devices[i];
-        if (split == MI355PT_SPLIT_SAMPLE) { p.sample_offset = params->sample_offset + i * params->sample_stride; p.sample_stride = params->sample_stride * num_shards; }
-        else if (num_shards > 1 || (params->tile_size > 0 && params->tile_stride > 1)) {
-            const uint32_t ts = params->tile_size ? params->tile_size : 64u, st = params->tile_size && params->tile_stride ? params->tile_stride : 1u;
-            p.tile_size = ts; p.tile_offset = (params->tile_size ? params->tile_offset : 0u) + i * st; p.tile_stride = st * num_shards;
-        }
-        if (int rc = mi355pt_render_create(g->shards[i].scene, &p, &g->shards[i].render)) return cleanup(rc);
-    }
-    // ---- read-out resources: per shard a packed buffer, per device a stream (and a communicator), the combined image on the first device
     for (auto& d : g->devs) { if (hipSetDevice(d.device) != hipSuccess || hipStreamCreateWithFlags(&d.stream, hipStreamNonBlocking) != hipSuccess) return cleanup(fail(MI355PT_ERR_HIP, "hipStreamCreate failed")); }
-    if (num_shards > 1 || g->use_rccl) {
-        for (auto& s : g->shards) { if (hipSetDevice(s.device) != hipSuccess || hipMalloc((void**)&s.pack, g->npix * sizeof(float4)) != hipSuccess) return cleanup(fail(MI355PT_ERR_HIP, "hipMalloc of the read-out buffer failed")); }
-        if (hipSetDevice(g->devs[0].device) != hipSuccess) return cleanup(fail(MI355PT_ERR_HIP, "hipSetDevice failed"));
-        if (int rc = g->out.alloc(g->npix)) return cleanup(rc);
-        if (hipEventCreate(&g->e0) != hipSuccess || hipEventCreate(&g->e1) != hipSuccess) return cleanup(fail(MI355PT_ERR_HIP, "hipEventCreate failed"));
-    }
+    if (hipSetDevice(g->devs[0].device) != hipSuccess || hipEventCreate(&g->e0) != hipSuccess || hipEventCreate(&g->e1) != hipSuccess) return cleanup(fail(MI355PT_ERR_HIP, "hipEventCreate failed"));
+    if (int rc = make_renderers(g.get(), params)) return cleanup(rc);
     if (g->use_rccl) {
         std::vector<ncclComm_t> comms(devlist.size(), nullptr);
         const ncclResult_t r = rccl()->CommInitAll(comms.data(), (int)devlist.size(), devlist.data());      // rank i = devs[i]: root 0 = the first device
@@ -262,8 +279,7 @@ int mi355pt_group_create(const mi355pt_scene_desc* desc, const int32_t* devices,
 
 void mi355pt_group_destroy(mi355pt_group* g) {
     if (!g) return;
-    for (auto& s : g->shards) if (s.render) mi355pt_render_destroy(s.render);
-    for (auto& s : g->shards) if (s.pack) { (void)hipSetDevice(s.device); (void)hipFree(s.pack); }
+    drop_renderers(g);
     for (auto& d : g->devs) {
         (void)hipSetDevice(d.device);
         if (d.comm && rccl()) (void)rccl()->CommDestroy(d.comm);
@@ -271,10 +287,20 @@ void mi355pt_group_destroy(mi355pt_group* g) {
         if (d.first_shard >= 0 && g->shards[d.first_shard].scene) mi355pt_scene_destroy(g->shards[d.first_shard].scene);
     }
     if (!g->devs.empty()) (void)hipSetDevice(g->devs[0].device);
-    g->out.release();
     if (g->e0) (void)hipEventDestroy(g->e0);
     if (g->e1) (void)hipEventDestroy(g->e1);
     delete g;
+}
+
+/* PathTracer::Init on a live group (src/pathtracer.cpp:13-21; RayTracer::Restart, src/raytracer.cpp:377-382): fresh accumulators
+ * of width x height on every shard, the uploaded scenes and the communicators kept. */
+int mi355pt_group_reset(mi355pt_group* g, uint32_t width, uint32_t height) {
+    if (!g || width == 0 || height == 0) return fail(MI355PT_ERR_INVALID, "bad argument");
+    std::lock_guard<std::mutex> lk(g->mu);
+    drop_renderers(g);
+    mi355pt_render_params p = g->tmpl;
+    p.width = width; p.height = height;
+    return make_renderers(g, &p);
 }
 
 uint32_t mi355pt_group_size(const mi355pt_group* g) { return g ? (uint32_t)g->shards.size() : 0u; }

@@ -5,8 +5,10 @@ so the path shards with no data-path collective: the scene is replicated and ran
 either sample indices g, g+G, g+2G, ... of every pixel (sample split) or every sample of the
 image tiles k with k % G == g (tile split); a pixel a rank does not own has count 0 there.  The reference averages tone-mapped
 samples (pathtracer.cpp:86-90), so the per-pixel value is linear in the samples and the
-read-out is ONE exchange: sum_g n_g * mean_g and sum_g n_g, reduced to rank 0 (RCCL over
-xGMI when the tensors live in HBM; gloo in the CPU tests).
+read-out is ONE exchange: sum_g n_g * mean_g and sum_g n_g, reduced to rank 0.  On GPUs that
+reduce runs INSIDE the library, on the accumulators in HBM (mi355pt_comm_* + mi355pt_render_reduce,
+or mi355pt_group_* for one process with several devices: RCCL over xGMI); `combine_running_means`
+below is the same arithmetic on host tensors, for the gloo tests and as bench.py's fallback.
 """
 import numpy as np
 
@@ -34,23 +36,6 @@ def tile_owner_mask(width, height, tile_size, tile_offset, tile_stride):
     y, x = np.divmod(np.arange(width * height, dtype=np.int64), width)
     tx = (width + tile_size - 1) // tile_size
     return ((y // tile_size) * tx + x // tile_size) % tile_stride == tile_offset
-
-
-class _DevArray:
-    """Zero-copy view of a device buffer for torch.as_tensor (CUDA array interface v2)."""
-
-    def __init__(self, ptr, shape, typestr):
-        self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": typestr, "data": (int(ptr), False), "version": 2}
-
-
-def accum_tensors(pt):
-    """The renderer's running-mean and count buffers as torch tensors aliasing HBM (no copy).
-    Call after `pt.sync()`: the buffers are written on the renderer's own stream."""
-    import torch
-    mean_ptr, cnt_ptr = pt.accum_device_ptrs()
-    mean = torch.as_tensor(_DevArray(mean_ptr, (pt.size, 3), "<f4"), device=f"cuda:{pt.dscene.device}")
-    cnt = torch.as_tensor(_DevArray(cnt_ptr, (pt.size,), "<i4"), device=f"cuda:{pt.dscene.device}")
-    return mean, cnt
 
 
 def combine_running_means(mean, cnt, dist=None, dst=0):

@@ -242,8 +242,10 @@ class PathTracerGroup:
         self.width = self.height = self.size = 0
 
     def Init(self, width, height):
-        self.close()
         self.width, self.height, self.size = int(width), int(height), int(width) * int(height)
+        if self.h:                                            # PathTracer::Init again: fresh accumulators, the uploaded scenes kept
+            capi.check(self.lib, self.lib.mi355pt_group_reset(self.h, self.width, self.height), "mi355pt_group_reset")
+            return
         desc, keep = self.scene.to_desc()
         prm = capi.make_params(self.width, self.height, **self._cfg)
         devs = (capi.i32 * len(self.devices))(*self.devices)

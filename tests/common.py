@@ -140,3 +140,30 @@ def attach_product_bvh(s, dscene):
         for c in n.children:
             walk(c)
     walk(s.rootNode)
+
+
+def converged_crop(pt, orc, rect, spp, threads=None, seeds=(0xB0B, 0xC0C), chunk=1 << 22):
+    """SURVEY 8(d)(3) on a crop: the tone-mapped mean image of `spp` samples per pixel of `rect` = (x0, y0, x1, y1) from the GPU
+    (seed = the renderer's, through mi355pt_sample_radiance: explicit (pixel, sample) pairs, averaged here) against the oracle's
+    with two OTHER seeds.  Returns (relMSE(gpu, oracle_B), relMSE(oracle_B, oracle_C)): the second is the Monte-Carlo noise floor
+    of two independent estimates; a bias shared by nobody shows as the first exceeding it."""
+    x0, y0, x1, y1 = rect
+    w = pt.width
+    ys, xs = np.mgrid[y0:y1, x0:x1]
+    pix = (ys * w + xs).astype(np.uint32).ravel()
+    acc = np.zeros((pix.size, 3), dtype=np.float64)
+    per = max(1, chunk // pix.size)                           # samples per call
+    for s0 in range(0, spp, per):
+        k = min(per, spp - s0)
+        pixel = np.tile(pix, k)
+        sample = np.repeat(np.arange(s0, s0 + k, dtype=np.uint32), pix.size)
+        _, mapped = pt.sample_radiance(pixel, sample)
+        acc += mapped.reshape(k, pix.size, 3).astype(np.float64).sum(axis=0)
+    gpu = (acc / spp).astype(np.float32)
+    threads = threads or max(1, min(16, (os.cpu_count() or 2) - 1))
+    prm_b = capi.make_params(pt.width, pt.height, seed=seeds[0])
+    prm_c = capi.make_params(pt.width, pt.height, seed=seeds[1])
+    ob, cb, _, _ = orc.render(prm_b, spp, rect=rect, threads=threads)
+    oc, cc, _, _ = orc.render(prm_c, spp, rect=rect, threads=threads)
+    assert (cb == spp).all() and (cc == spp).all()
+    return rel_mse(gpu, ob), rel_mse(ob, oc), gpu, ob

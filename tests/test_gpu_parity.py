@@ -345,6 +345,11 @@ def test_full_size_10m_triangle_scene(monkeypatch):
     frac, _ = common.radiance_agreement(a[:3000], olin)
     assert frac >= 0.999
     p2.close_render()
+    # SURVEY 8(d)(3) for C4: a converged crop of the full-size frame, GPU (this renderer's seed) against the oracle with two other
+    # seeds -- relMSE <= 1e-3 and within twice the oracle-vs-oracle noise floor (tests/test_gpu_convergence.py has C1-C3)
+    r, floor, gpu, ob = common.converged_crop(pt, orc, (1888, 1062, 1952, 1098), 2048)
+    print(f"c4 crop: relMSE gpu-vs-oracle {r:.3e}, oracle-vs-oracle noise floor {floor:.3e} at 2048 spp")
+    assert gpu.max() > 0.05 and r <= 1e-3 and r <= 2.0 * floor + 2e-5, (r, floor)
     pt.close_render()
 
 

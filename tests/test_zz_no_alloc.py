@@ -9,6 +9,7 @@ import ctypes as C
 import numpy as np
 import pytest
 
+from oracle.binding import OracleScene
 from pathtracer_amd import PathTracer, capi
 from tests import common
 
@@ -104,18 +105,26 @@ def test_static_entry_matches_trace_rays(name):
         for a, b in zip(got[:3], want[:3]):
             assert np.array_equal(a, b)
         assert np.array_equal(got[3].view(np.uint32), want[3].view(np.uint32)), "t must be bit-identical"
+        if n <= 7001:              # ... and against the oracle's TraceNode (exhaustive walk): the static path's own parity evidence
+            on, om, of, ot = OracleScene(s).trace_rays(o, d)
+            assert np.array_equal(got[0], on) and np.array_equal(got[1], om) and np.array_equal(got[2], of)
+            assert np.array_equal(got[3].view(np.uint32), ot.view(np.uint32))
     pt.close_render()
 
 
-def test_static_entry_rejects_oversize_and_null():
-    mk, w, h = common.small_scenes()["cornell_c1"]
-    pt = PathTracer(mk(w, h))
-    pt.Init(w, h)
-    lib = pt.lib
-    hip = _Hip()
-    p = hip.alloc(64)
-    rc = lib.mi355pt_trace_rays_static(pt.dscene.h, p, p, capi.STATIC_MAX_RAYS + 1, p, p, p, p, None)
-    assert rc == -5 and b"MI355PT_STATIC_MAX_RAYS" in lib.mi355pt_last_error()
-    assert lib.mi355pt_trace_rays_static(pt.dscene.h, None, p, 4, p, p, p, p, None) == -1
-    assert lib.mi355pt_trace_rays_static(pt.dscene.h, p, p, 0, p, p, p, p, None) == 0
+def test_static_entry_takes_the_exact_walk_switch(monkeypatch):
+    """MI355PT_NO_CULL -- the exhaustive walk of the reference, the switch for callers that need its answer on grazing rays
+     -- reaches the static entry point too (it is read when the scene is created): on the
+    adversarial shingle scene of tests/test_gpu_soup_cull.py the static path then agrees with the oracle on every ray."""
+    from tests.test_gpu_soup_cull import CENTERS, _grazing_rays, _shingles
+    center, size = CENTERS["1e4"]
+    s, stack, _ = _shingles(center, size)
+    o, d, L, c = _grazing_rays(stack, size, 40000, 9)
+    monkeypatch.setenv("MI355PT_NO_CULL", "1")
+    pt = PathTracer(s)                          # the scene reads the switch when it is created
+    pt.Init(32, 32)
+    got = _static_trace(pt.lib, _Hip(), pt.dscene, o, d)
+    on, om, of, ot = OracleScene(s).trace_rays(o, d)
+    assert (on >= 0).mean() > 0.5
+    assert np.array_equal(got[0], on) and np.array_equal(got[2], of) and np.array_equal(got[3].view(np.uint32), ot.view(np.uint32))
     pt.close_render()
