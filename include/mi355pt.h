@@ -351,7 +351,12 @@ int mi355pt_render_set_overlap(mi355pt_render* render, uint32_t from_bounce);
  * hipMalloc / hipFree or any allocating routine, needs no renderer, and rejects count > MI355PT_STATIC_MAX_RAYS
  * with MI355PT_ERR_TOO_LARGE.  All calls on one GPU share that GPU's array: calls that overlap on one GPU
  * (different streams, or different host threads) race; serialise them on one stream.  A traversal that trips
- * its internal pass guard poisons the outputs (ids -2, t = NaN) since no status can be read back without a copy. */
+ * its internal pass guard poisons the outputs (ids -2, t = NaN) since no status can be read back without a copy.
+ * Lifetime: the call only ENQUEUES, and the enqueued kernels read the scene's tables in HBM -- the scene must outlive
+ * that work (mi355pt_scene_destroy only after `stream` has drained; a scene already destroyed is rejected with
+ * MI355PT_ERR_INVALID).  `stream` must belong to the scene's device; the calling thread's current device is restored on
+ * return.  The traversal switches of the environment (MI355PT_NO_CULL, MI355PT_STACK_WINDOW, ...) are read when the
+ * scene is created and apply to this entry point as they do to a renderer. */
 #define MI355PT_STATIC_MAX_RAYS 131072u
 int mi355pt_trace_rays_static(mi355pt_scene* scene, const float* d_origins, const float* d_dirs, uint32_t count,
                               int32_t* d_node, int32_t* d_mesh, int32_t* d_face, float* d_t, void* stream);

@@ -51,6 +51,9 @@ struct DPaths {
     float4   *ray;        // 2 x cap: (origin, -), (direction, -) of the ray to trace next
     float4   *T, *C;      // throughput, accumulated radiance
     uint4    *hit;        // closest-hit record: (t bits, instance, mesh, triangle slot)
+    int32_t  *qhit;       // per QUEUE INDEX of the current bounce: the instance the ray hit, -1 = none.  Written beside the hit record by
+                          // whoever finishes the ray; k_shade's gather reads it (and the queue) coalesced instead of probing hit[slot]
+                          // -- one scattered 64-B sector per queue entry, 22 GB per C4 step (nullptr in the static entry's DPaths)
     float4   *sh;         // shv x cap, record-major: NEE / MIS work of the current bounce
     uint32_t  shv;        // pieces per shadow record (6 or 7, see SHV_HP)
     uint32_t *queue[2];   // path-slot indices, ping-pong
@@ -114,7 +117,7 @@ __device__ __forceinline__ uint32_t xcd_block(uint32_t b, uint32_t nb) {
 
 // One ray of k_prepare (below): the object walk up to the first mesh `wr` must traverse.
 // Returns true when the ray was finished here (no mesh in its way).
-__device__ __forceinline__ bool prepare_ray(const DScene& S, const DPaths& P, uint32_t slot, Ray wr) {
+__device__ __forceinline__ bool prepare_ray(const DScene& S, const DPaths& P, uint32_t slot, uint32_t qidx, Ray wr) {
     if (S.num_recs > 0) wr = rec_ray(S, S.recs, 1u, 0u, wr);
     float best_t = kBig; int best_inst = -1;
     uint32_t rec = 0;
@@ -158,6 +161,7 @@ __device__ __forceinline__ bool prepare_ray(const DScene& S, const DPaths& P, ui
         A[2] = make_float4(inv.x, inv.y, inv.z, __uint_as_float(rec)); A[3] = make_float4(__uint_as_float(root_ref), __uint_as_float(root_cnt), 0.0f, 0.0f);
     } else {
         store_hit(P, slot, best_t, best_inst, -1, 0u);
+        P.qhit[qidx] = best_inst;
         A[2] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(0xFFFFFFFFu));
     }
     return !found;
@@ -208,7 +212,7 @@ __global__ void __launch_bounds__(kBlock) k_init(DPaths P, Params prm, uint32_t 
             Ray r; F3 rd, td;
             camera_rays(cam, prm.seed, pixel, sample, prm.width, true, r, rd, td);
             P.ray[2 * (size_t)i] = f4(r.p, 0.0f); P.ray[2 * (size_t)i + 1] = f4(r.d, 0.0f);
-            if (with_rays == 2u && prepare_ray(S, P, i, r)) fin++;       // bounce 0's set-up pre-pass in the same pass (k_prepare)
+            if (with_rays == 2u && prepare_ray(S, P, i, i, r)) fin++;       // bounce 0's set-up pre-pass in the same pass (k_prepare)
         }
     }
     if (with_rays == 2u) wave_add64(fin, &P.stat[18]);
@@ -320,7 +324,7 @@ __global__ void __launch_bounds__(kBlock) k_prepare(DScene S, DPaths P, uint32_t
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const uint32_t slot = q ? q[i] : i;
         Ray wr; wr.p = xyz(P.ray[2 * (size_t)slot]); wr.d = xyz(P.ray[2 * (size_t)slot + 1]);
-        prepare_ray(S, P, slot, wr);
+        prepare_ray(S, P, slot, i, wr);
     }
 }
 
@@ -373,6 +377,7 @@ __global__ void __launch_bounds__(kExtBlockMax) k_trace(DScene S, DPaths P, Para
 #define PT_SPILL(i) ((PT_GLOBAL_AS uint32_t*)spill)[(i) * 64 + lane]      // (explicit: `cond ? PT_STK(i) : PT_SPILL(i)` must not become one flat load)
     WorkCounters wc; wc.nodes = 0; wc.tris = 0; wc.top = 0;
     uint32_t state = LS_IDLE, slot = 0, rec = 0, sp = 0, sb = 0, lo = 0, owner = lane;
+    uint32_t qidx = 0;                                                                     // closest: the ray's position in the bounce's queue (P.qhit)
     F3 o = f3(0, 0, 0), inv = f3(0, 0, 0);
     float bt = kBig, pabs = 0.0f, bmarg = 0.0f;
     bool fastok = false;                                                                  // this lane's ray may take slab_pair_fast
@@ -455,6 +460,7 @@ __global__ void __launch_bounds__(kExtBlockMax) k_trace(DScene S, DPaths P, Para
                         if (idx < pool_end) {
                             slot = q ? ((const PT_GLOBAL_AS uint32_t*)q)[idx] : idx;      // (q is picked from an array of pointers: say where it points)
                             rec = 0; state = LS_SETUP;
+                            if (MODE == 0) qidx = idx;
                             if (MODE == 0 && use_prep) {                      // k_prepare has walked this ray up to its first mesh
                                 const float4* A = P.prep + 4 * (size_t)slot;
                                 const float4 a0 = A[0], a1 = A[1], a2 = A[2], a3 = A[3];
@@ -578,7 +584,7 @@ __global__ void __launch_bounds__(kExtBlockMax) k_trace(DScene S, DPaths P, Para
                         if (rec >= (OWN ? rec_end : (uint32_t)S.num_recs)) {
                             if (ANY) P.vis[slot] = 0;
                             else if (OWN) P.lhit[slot] = make_uint4(__float_as_uint(best_t), (uint32_t)best_inst, (uint32_t)best_mesh, best_slot);
-                            else store_hit(P, slot, best_t, best_inst, best_mesh, best_slot);
+                            else { store_hit(P, slot, best_t, best_inst, best_mesh, best_slot); if (P.qhit) P.qhit[qidx] = best_inst; }
                             state = LS_IDLE;
                             break;
                         }
@@ -772,7 +778,7 @@ __global__ void __launch_bounds__(kExtBlockMax) k_trace(DScene S, DPaths P, Para
             if (state == LS_SETUP && rec >= (OWN ? rec_end : (uint32_t)S.num_recs)) {      // that was the last object: report now, the lane is idle
                 if (ANY) P.vis[slot] = 0;
                 else if (OWN) P.lhit[slot] = make_uint4(__float_as_uint(best_t), (uint32_t)best_inst, (uint32_t)best_mesh, best_slot);
-                else store_hit(P, slot, best_t, best_inst, best_mesh, best_slot);
+                else { store_hit(P, slot, best_t, best_inst, best_mesh, best_slot); if (P.qhit) P.qhit[qidx] = best_inst; }
                 state = LS_IDLE;
             }
         }
@@ -990,9 +996,12 @@ k_shade(DScene S, DCamera cam, DPaths P, Params prm, uint32_t bounce, uint32_t n
             uint32_t gslot = 0;
             if (i < n) {
                 gslot = q ? q[i] : i;
-                const int hinst = (int)P.hit[gslot].y;
+                const int hinst = P.qhit[i];                      // (coalesced, like the queue entry: no probe of hit[gslot])
                 if (hinst < 0) {
-                    if (do_miss) {
+                    // A miss adds throughput * environment (render.h:124-128).  With a black, map-less environment that is C + T * 0:
+                    // C itself unless a component of T is not finite -- and such a path was marked when k_shade wrote that T
+                    // (below), so the miss touches no memory at all.
+                    if (do_miss && !S.env_black) {
                         const F3 dir = xyz(P.ray[2 * (size_t)gslot + 1]);
                         const F3 C = xyz(P.C[gslot]) + xyz(P.T[gslot]) * sample_environment(S, dir);
                         P.C[gslot] = f4(C, 0.0f);
@@ -1045,6 +1054,7 @@ k_shade(DScene S, DCamera cam, DPaths P, Params prm, uint32_t bounce, uint32_t n
                 wo = wo / len(wo);
                 MatCtx m;
                 mat_prepare<KIND, ATLAS>(S, h, m);
+                mat_view(m, wo);
 #ifdef PT_SHADE_PROBE
                 asm volatile("" :: "v"(m.brdfN.x), "v"(h.p.x) : "memory");
                 PT_SHADE_TICK(pk_surf)
@@ -1127,6 +1137,10 @@ k_shade(DScene S, DCamera cam, DPaths P, Params prm, uint32_t bounce, uint32_t n
                     else T = T * (1.0f / p);
                 }
                 if (bounce + 1 >= prm.max_bounces) alive = false;
+                // Black environment (see the gather): a path that goes on with a non-finite throughput ends black whatever it meets next
+                // -- a miss adds T * 0 = NaN, a hit adds T * (direct / selectPdf), NaN or Inf (the scene has lights: env_black) -- and the
+                // sample is zeroed at the end (render.h:218-223).  Marking it here is what lets the misses go untouched.
+                if (alive && S.env_black && !(isfinite(T.x) && isfinite(T.y) && isfinite(T.z))) C.x = __uint_as_float(0x7FC00000u);
                 P.C[slot] = f4(C, 0.0f);
                 if (alive) {
                     P.T[slot] = f4(T, 0.0f);
@@ -1238,6 +1252,7 @@ __global__ void __launch_bounds__(kBlock) k_closest_analytic(DScene S, DPaths P,
             if (hit && t < best_t) { best_t = t; best_inst = (int)rii; }      // an earlier object wins ties (raytracer.cpp:208)
         }
         store_hit(P, slot, best_t, best_inst, -1, 0u);
+        P.qhit[i] = best_inst;
     }
 }
 
@@ -1624,6 +1639,8 @@ int upload_scene(const pth::SceneView& v, int32_t device, std::shared_ptr<std::v
     d.recs = sc->recs.p; d.num_recs = (int)(n_recs / kRecStride);
     d.top_base = H.top_base; d.top_count = H.top_count;
     memcpy(d.env_color, H.env_color, sizeof(d.env_color)); d.env_map = H.env_map;
+    // (the reference's default: `environment` is (0, 0, 0) unless the scene file says otherwise, scene.h:262; MI355PT_NO_BLACK_ENV: A/B and test switch)
+    d.env_black = (H.env_map < 0 && H.env_color[0] == 0.0f && H.env_color[1] == 0.0f && H.env_color[2] == 0.0f && n_li > 0 && !getenv("MI355PT_NO_BLACK_ENV")) ? 1 : 0;
     // Texture::Sample tap offsets (scene.h:169-175), host libm like the reference: the same 64 floats for every scene.  They live in
     // constant memory of the device (g_filter_taps, pt_shade.h), not in an array inside DScene: k_shade's TABLES instances change
     // four pointers of their DScene, and a struct with a dynamically indexed array in it lives in scratch memory from then on,
@@ -1918,7 +1935,7 @@ void free_pool(mi355pt_render* r) {
     for (void* p : r->pool_allocs) (void)hipFree(p);
     r->pool_allocs.clear();
     DPaths& P = r->P;
-    P.cap = 0; P.id = nullptr; P.ray = nullptr; P.T = P.C = nullptr; P.hit = nullptr; P.sh = nullptr; P.queue[0] = P.queue[1] = nullptr;
+    P.cap = 0; P.id = nullptr; P.ray = nullptr; P.T = P.C = nullptr; P.hit = nullptr; P.qhit = nullptr; P.sh = nullptr; P.queue[0] = P.queue[1] = nullptr;
     P.squeue = nullptr; P.vqueue = nullptr; P.lhit = nullptr; P.prep = nullptr; P.vis = nullptr;
 }
 hipError_t alloc_pool(mi355pt_render* r, size_t cap) {
@@ -1926,7 +1943,7 @@ hipError_t alloc_pool(mi355pt_render* r, size_t cap) {
     auto get = [&](void** p, size_t bytes) -> hipError_t { hipError_t e = hipMalloc(p, bytes); if (e == hipSuccess) r->pool_allocs.push_back(*p); return e; };
     hipError_t e;
 #define PT_GET(ptr, bytes) if ((e = get((void**)&(ptr), (bytes))) != hipSuccess) return e
-    PT_GET(P.id, cap * 16); PT_GET(P.ray, cap * 32); PT_GET(P.T, cap * 16); PT_GET(P.C, cap * 16); PT_GET(P.hit, cap * 16);
+    PT_GET(P.id, cap * 16); PT_GET(P.ray, cap * 32); PT_GET(P.T, cap * 16); PT_GET(P.C, cap * 16); PT_GET(P.hit, cap * 16); PT_GET(P.qhit, cap * 4);
     PT_GET(P.sh, cap * 16 * P.shv); PT_GET(P.queue[0], cap * 4); PT_GET(P.queue[1], cap * 4); PT_GET(P.squeue, cap * 4); PT_GET(P.vqueue, cap * 8);
     if (r->scene->model_lights) PT_GET(P.lhit, cap * 2 * sizeof(uint4));
     if (r->prep_bounces) PT_GET(P.prep, cap * 4 * sizeof(float4));
@@ -1951,7 +1968,7 @@ int ensure_pool(mi355pt_render* r, size_t want, size_t floor) {
         (void)hipGetLastError();                                   // clear the sticky out-of-memory status
         if (e != hipErrorOutOfMemory) return fail(MI355PT_ERR_HIP, std::string("path pool: ") + hipGetErrorString(e));
         r->pool_oom_at = cap;
-        if (cap <= floor) return fail(MI355PT_ERR_HIP, "path pool: out of device memory for " + std::to_string(cap) + " path slots of " + std::to_string(90 + 16 * r->P.shv + (r->scene->model_lights ? 32 : 0) + (r->prep_bounces ? 64 : 0)) + " B (MI355PT_MAX_PATHS lowers the limit)");
+        if (cap <= floor) return fail(MI355PT_ERR_HIP, "path pool: out of device memory for " + std::to_string(cap) + " path slots of " + std::to_string(122 + 16 * r->P.shv + (r->scene->model_lights ? 32 : 0) + (r->prep_bounces ? 64 : 0)) + " B (MI355PT_MAX_PATHS lowers the limit)");
         cap = std::max(floor, ((cap / 2) + 63) & ~(size_t)63);
     }
 }

@@ -75,6 +75,7 @@ struct DScene {
     int             plane_lights_only;   // every light sits on a Plane: the kernels take the short analytic path (uniform branch)
     const float4*   recs;       int num_recs;
     float env_color[3];         int env_map;
+    int env_black;              // the environment is the constant (0, 0, 0) and the scene has lights: a miss changes nothing (k_shade)
 };
 
 }  // namespace ptd

@@ -318,6 +318,11 @@ struct Disney {
     F3 base;
     float metallic, specular, roughness, specularTint, sheenTint, sheen, clearcoatGloss, clearcoat, subsurface, csw;
     float a_eval, log_eval, a_pdf, log_pdf;      // clearcoat GTR1 widths of DisneyEval / DisneyPdf and log(a * a) of each
+    // DisneyEval's terms that depend on the material and on wo only (disney_view): a vertex evaluates the BRDF three times (light
+    // sample, MIS sample, continuation) for one wo.  Each evaluation sits behind its own `NdotL <= 0` exit, so the compiler cannot
+    // share them between the calls; computed once here they are the same expressions, hence the same bits.
+    F3 c_spec0, c_sheen;
+    float ro, ro2, f_wo, g_wo, gr_wo;
 };
 PT_DEV void disney_finish(Disney& s) {      // Clamp + InitCSW (disneyBrdf.h:108-131)
     s.metallic = dclamp(s.metallic, 0.001f, 0.999f); s.specular = dclamp(s.specular, 0.001f, 0.999f);
@@ -333,6 +338,12 @@ PT_DEV void disney_finish(Disney& s) {      // Clamp + InitCSW (disneyBrdf.h:108
     s.csw = cs_lum / (cs_lum + (1.0f - s.metallic) * cd_lum);
     s.a_eval = mixf(0.1f, 0.001f, s.clearcoatGloss); s.log_eval = a_logf(s.a_eval * s.a_eval);
     s.a_pdf = mixf(0.1f, 0.001f, s.a_eval); s.log_pdf = a_logf(s.a_pdf * s.a_pdf);
+    // DisneyEval's own c_spec0 (0.3 * specular, where InitCSW has 1 - 0.3 * specular: disneyBrdf.h:127 vs :166) and c_sheen
+    s.c_spec0 = mixv(s.specular * 0.3f * mixv(f3(1, 1, 1), c_tint, s.specularTint), cd, s.metallic);
+    s.c_sheen = mixv(f3(1, 1, 1), c_tint, s.sheenTint);
+    s.ro = dmax(0.001f, s.roughness);
+    const float r2 = s.roughness * 0.5f + 0.5f;
+    s.ro2 = r2 * r2;
 }
 PT_DEV float disney_pdf(const Disney& s, float NdotH, float NdotL, float HdotL) {
     const float d_pdf = NdotL * (1.0f / kPI);
@@ -340,31 +351,30 @@ PT_DEV float disney_pdf(const Disney& s, float NdotH, float NdotL, float HdotL) 
     const float c_pdf = gtr1(NdotH, s.a_pdf, s.log_pdf) * NdotH / (4.0f * HdotL);
     return c_pdf * s.clearcoat + (1.0f - s.clearcoat) * (s.csw * r_pdf + (1.0f - s.csw) * d_pdf);
 }
+// the wo-dependent terms of DisneyEval (disneyBrdf.h:176-205) for the vertex's NdotV
+PT_DEV void disney_view(Disney& s, float NdotV) {
+    s.f_wo = schlick(NdotV);
+    s.g_wo = smith_ggx(NdotV, s.ro2);
+    s.gr_wo = smith_ggx(NdotV, 0.25f);
+}
 PT_DEV F3 disney_eval(const Disney& s, float NdotL, float NdotV, float NdotH, float HdotL) {
     if (NdotL <= 0.0f || NdotV <= 0.0f) return f3(0, 0, 0);
     const F3 cd = s.base;
-    const float cd_lum = dot(cd, f3(0.3f, 0.6f, 0.1f));
-    const F3 c_tint = cd_lum > 0.0f ? (cd / cd_lum) : f3(1, 1, 1);
-    const F3 c_spec0 = mixv(s.specular * 0.3f * mixv(f3(1, 1, 1), c_tint, s.specularTint), cd, s.metallic);
-    const F3 c_sheen = mixv(f3(1, 1, 1), c_tint, s.sheenTint);
-    const float f_wo = schlick(NdotV), f_wi = schlick(NdotL);
+    const float f_wo = s.f_wo, f_wi = schlick(NdotL);
     const float fd90 = 0.5f + 2.0f * HdotL * HdotL * s.roughness;
     const float fd = mixf(1.0f, fd90, f_wo) * mixf(1.0f, fd90, f_wi);
     const float fss90 = HdotL * HdotL * s.roughness;
     const float fss = mixf(1.0f, fss90, f_wo) * mixf(1.0f, fss90, f_wi);
     const float ss = 1.25f * (fss * (1.0f / (NdotV + NdotL) - 0.5f) + 0.5f);
-    const float ro = dmax(0.001f, s.roughness);
-    const float ds = gtr2(NdotH, ro);
+    const float ds = gtr2(NdotH, s.ro);
     const float fh = schlick(HdotL);
-    const F3 fs = mixv(c_spec0, f3(1, 1, 1), fh);
-    const float r2 = s.roughness * 0.5f + 0.5f;
-    const float ro2 = r2 * r2;
-    float gs = smith_ggx(NdotV, ro2);
-    gs *= smith_ggx(NdotL, ro2);
-    const F3 f_sheen = fh * s.sheen * c_sheen;
+    const F3 fs = mixv(s.c_spec0, f3(1, 1, 1), fh);
+    float gs = s.g_wo;
+    gs *= smith_ggx(NdotL, s.ro2);
+    const F3 f_sheen = fh * s.sheen * s.c_sheen;
     const float dr = gtr1(NdotH, s.a_eval, s.log_eval);
     const float fr = mixf(0.04f, 1.0f, fh);
-    const float gr = smith_ggx(NdotV, 0.25f) * smith_ggx(NdotL, 0.25f);
+    const float gr = s.gr_wo * smith_ggx(NdotL, 0.25f);
     const F3 f = ((1.0f / kPI) * mixf(fd, ss, s.subsurface) * cd + f_sheen) * (1.0f - s.metallic) + gs * fs * ds + (0.25f * s.clearcoat) * gr * fr * dr;
     return f * NdotL;
 }
@@ -476,6 +486,7 @@ struct MatCtx {
     Disney d;
     F3 brdfN, Ngeo, albedo, emission;
     float rough_raw, rough_eval, metal;
+    float NdotV;                 // Disney: dot(brdfN, wo) of this vertex (mat_view)
 };
 // KIND >= 0: the caller knows the material kind (k_shade<KIND> only takes hits of that kind): the other model's code, and
 // the registers its values would occupy, drop out at compile time.
@@ -548,10 +559,14 @@ PT_DEV void mat_sample(const MatCtx& m, F3 wo, Rng& rng, F3& wi, float& pdf) {
         wi = sd / len(sd);
     }
 }
+// once per vertex, after mat_prepare: the terms of the BRDF evaluations that depend on wo only
+PT_DEV void mat_view(MatCtx& m, F3 wo) {
+    if (m.kind == MI355PT_MTL_DISNEY) { m.NdotV = dot(m.brdfN, wo); disney_view(m.d, m.NdotV); }
+}
 PT_DEV F3 mat_eval(const MatCtx& m, F3 wi, F3 wo) {      // shadingNormal output == m.brdfN for both materials
     if (m.kind == MI355PT_MTL_DISNEY) {
         const F3 H = normalized(wi + wo);
-        return m.emission + disney_eval(m.d, dot(m.brdfN, wi), dot(m.brdfN, wo), dot(m.brdfN, H), dot(H, wi));
+        return m.emission + disney_eval(m.d, dot(m.brdfN, wi), m.NdotV, dot(m.brdfN, H), dot(H, wi));
     }
     return cook_torrance(wi, wo, m.Ngeo, m.albedo, m.rough_eval, m.metal);
 }

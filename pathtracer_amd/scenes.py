@@ -1,7 +1,7 @@
 """Scene builders for the BASELINE.json configurations (C1..C5).
 
 Everything here is host-side scene construction through the object model of scene.py;
-nothing on the hot path.  Mesh data files live in tests/golden/assets (data fixtures
+nothing on the hot path.  Mesh data files live in pathtracer_amd/assets (data files
 taken from the reference's assets/ directory); texture maps are synthetic (seeded)
 because the reference's 1024^2 PNGs do not travel to the GPU box.
 """
@@ -12,7 +12,7 @@ import numpy as np
 from .scene import (Camera, LightComponent, Mesh, Model, MtlDisney, MtlStandard, Node, Plane, Scene, Sphere,
                     TextureChecker, TextureFile, TextureMap, load_obj, F)
 
-ASSETS = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "assets")
+ASSETS = os.path.join(os.path.dirname(os.path.abspath(__file__)), "assets")      # the package's own data: nothing here reaches into tests/
 
 
 def _plane(name, mtl, scale=None, rotate=None, translate=None, light=None):

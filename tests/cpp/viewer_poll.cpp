@@ -5,7 +5,7 @@
 // "output buffer file" saves colorbuffer.png (:461-474).  This harness does the same against
 // include/mi355pt_pathtracer.hpp: one thread renders, this thread polls on the reference's 0.3 s timer, then pause,
 // restart, PNG out.
-//   usage: viewer_poll <out.png> <width> <height> <polls>
+//   usage: viewer_poll <out.png> <width> <height> <polls> [samples per step]
 // Prints one line per poll and, last, "final samples=<S>": tests/test_cpp_host.py renders S samples through the Python
 // mirror and compares the PNG byte for byte.
 // Exit codes: 0 ok, 2 usage, 3 library error (e.g. no gfx950 device: there is no fallback), 4 a viewer-loop check failed.
@@ -60,7 +60,7 @@ static uint32_t frame_sum(const std::vector<uint8_t>& v) { crc_init(); return cr
 #define REQUIRE(cond, msg) do { if (!(cond)) { fprintf(stderr, "viewer_poll: %s\n", msg); return 4; } } while (0)
 
 int main(int argc, char** argv) {
-    if (argc != 5) { fprintf(stderr, "usage: %s <out.png> <width> <height> <polls>\n", argv[0]); return 2; }
+    if (argc != 5 && argc != 6) { fprintf(stderr, "usage: %s <out.png> <width> <height> <polls> [samples per step]\n", argv[0]); return 2; }
     const unsigned w = (unsigned)atoi(argv[2]), h = (unsigned)atoi(argv[3]);
     const int polls = atoi(argv[4]);
     const auto tick = std::chrono::milliseconds(300);           // updateTimer > 0.3f, src/window.cpp:170
@@ -68,6 +68,7 @@ int main(int argc, char** argv) {
     try {
         mi355pt::PathTracer pt(scene.desc);
         pt.Init(w, h);
+        if (argc == 6) pt.SetSamplesPerStep((uint32_t)atoi(argv[5]));      // a fixed batch (the default grows it to ~0.1 s per step)
         pt.Run();                                               // the tracing thread; this one is the GUI thread
         std::vector<uint8_t> frame, prev;
         uint64_t last = 0;

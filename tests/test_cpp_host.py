@@ -106,7 +106,9 @@ def test_viewer_loop_polls_pauses_restarts_and_saves(tmp_path):
     from pathtracer_amd.scene import load_png_rgb8
     w, h, polls = 160, 120, 4
     out = tmp_path / "colorbuffer.png"
-    r = subprocess.run([_ensure_demo(VIEWER), str(out), str(w), str(h), str(polls)], capture_output=True, text=True, timeout=300)
+    # two samples per step: the loop then reaches a few thousand samples per pixel, which the oracle can follow (the default,
+    # adaptive batch renders tens of thousands in the same 1.5 s)
+    r = subprocess.run([_ensure_demo(VIEWER), str(out), str(w), str(h), str(polls), "2"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     lines = r.stdout.strip().splitlines()
     counts = [int(l.split("samples=")[1].split()[0]) for l in lines if l.startswith("poll ")]

@@ -729,3 +729,60 @@ def test_shade_tables_in_lds_same_results(built, name, monkeypatch):
     assert np.array_equal(ma.view(np.uint32), mb.view(np.uint32)) and np.array_equal(ca, cb)
     assert sb["shadow_rays"] > 0
     p2.close_render()
+
+
+def _degenerate_pdf_scene(w, h):
+    """Open scene (most paths leave it) whose materials drive BRDF pdfs to 0 and throughputs to Inf / NaN on some paths: mirror-like
+    Cook-Torrance (roughness at its floor) and a metallic, rough-free Disney surface under a small light."""
+    from pathtracer_amd import scene as sc, scenes
+    s = sc.Scene()
+    s.camera = sc.Camera((0, -26, 9), (0, 0, 2), (0, 0, 1), fov=40.0, width=w, height=h)
+    a = sc.MtlStandard("mirror", albedo=(0.95, 0.95, 0.95), roughness=0.0, metalness=1.0)
+    b = sc.MtlDisney("slick", albedo=(0.9, 0.8, 0.7), roughness=np.float32(0.0), metalness=np.float32(1.0), specular=1.0, clearcoat=1.0, clearcoat_gloss=1.0)
+    s.materials = [a, b]
+    s.rootNode.AppendChild(scenes._plane("Floor", a, 14.0))
+    k = s.rootNode.AppendChild(sc.Node("ball", sc.Sphere(), b)); k.Scale(3.0); k.Translate((0, 0, 3))
+    s.rootNode.AppendChild(scenes._plane("QuadLight", a, 1.5, ((1, 0, 0), 180.0), (3, -2, 11), light=30.0))
+    return s
+
+
+@pytest.mark.parametrize("name", ["grid_small", "textured_c2", "teapot_cornell", "degenerate_pdf"])
+def test_black_environment_misses_same_results(built, name, monkeypatch):
+    """With the reference's default environment -- the constant (0, 0, 0), scene.h:262 -- a miss adds throughput * 0: k_shade's
+    gather then skips misses altogether, and a path that continues with a non-finite throughput is marked where that throughput
+    is written (it ends black whatever it meets).  MI355PT_NO_BLACK_ENV (read at scene creation) runs the literal
+    `color += throughput * environment` instead: same per-sample radiance, same accumulators, same ray counts, bit for bit --
+    including on paths whose throughput does become Inf / NaN (degenerate_pdf), which the oracle renders the same way."""
+    from oracle.binding import OracleScene
+    from pathtracer_amd import DeviceScene
+    if name == "degenerate_pdf":
+        w, h = 96, 72
+        s = _degenerate_pdf_scene(w, h)
+        pt = PathTracer(s); pt.Init(w, h)
+        orc = OracleScene(s)
+    else:
+        s, orc, pt, w, h = built(name)
+    rng = np.random.default_rng(29)
+    pixel = rng.integers(0, w * h, 6000).astype(np.uint32)
+    sample = rng.integers(0, 64, 6000).astype(np.uint32)
+    a, am = pt.sample_radiance(pixel, sample)
+    pt.Init(w, h); pt.step(3); pt.sync()
+    ma, ca = pt.read_accum()
+    sa = pt.stats()
+    monkeypatch.setenv("MI355PT_NO_BLACK_ENV", "1")
+    p2 = PathTracer(DeviceScene(s))
+    monkeypatch.delenv("MI355PT_NO_BLACK_ENV")
+    p2.Init(w, h)
+    b, bm = p2.sample_radiance(pixel, sample)
+    p2.Init(w, h); p2.step(3); p2.sync()
+    mb, cb = p2.read_accum()
+    sb = p2.stats()
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32)) and np.array_equal(am.view(np.uint32), bm.view(np.uint32))
+    assert np.array_equal(ma.view(np.uint32), mb.view(np.uint32)) and np.array_equal(ca, cb)
+    assert sa["closest_rays"] == sb["closest_rays"] and sa["shadow_rays"] == sb["shadow_rays"]
+    if name == "degenerate_pdf":
+        olin, _ = orc.sample_radiance(pt.params, pixel, sample)
+        frac, _ = common.radiance_agreement(a, olin)
+        assert frac >= 0.999 and np.isfinite(a).all()
+        pt.close_render()
+    p2.close_render()
