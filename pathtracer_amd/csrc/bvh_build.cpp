@@ -3,6 +3,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <cstdlib>
 #include <cstring>
 #include <thread>
 
@@ -305,13 +306,40 @@ void flatten_tree(const MeshTree& t, FlatMesh& out) {
             if (t.nodes[s.left].left >= 0) bfs.push_back(s.left);
             if (t.nodes[s.right].left >= 0) bfs.push_back(s.right);
         }
-        std::vector<int> st; st.push_back(0);
-        while (!st.empty()) {
-            int n = st.back(); st.pop_back();
-            const TmpNode& s = t.nodes[n];
-            if (s.left < 0) continue;
-            if (rec[n] < 0) rec[n] = nrec++;
-            st.push_back(s.right); st.push_back(s.left);
+        // MI355PT_RECORD_ORDER (A/B knob): "pre" = left-first pre-order (a node's left child follows it),
+        // "treeletK" = subtrees of up to K internal nodes, breadth-first inside, stored contiguously (K = 2..64): a ray's next few
+        // steps then stay within K x 64 B.  Only the ORDER of the records changes; the tree, the slots and every result are the same.
+        int treelet = 0;
+        if (const char* e = getenv("MI355PT_RECORD_ORDER")) if (!strncmp(e, "treelet", 7)) treelet = std::max(2, std::min(64, atoi(e + 7)));
+        if (treelet) {
+            std::vector<int> roots; roots.push_back(0);           // treelet roots, depth-first over treelets
+            std::vector<int> q;
+            while (!roots.empty()) {
+                const int r0 = roots.back(); roots.pop_back();
+                if (t.nodes[r0].left < 0) continue;
+                q.clear(); q.push_back(r0);
+                std::vector<int> frontier;
+                int taken = 0;
+                for (size_t h = 0; h < q.size(); h++) {
+                    const int n = q[h];
+                    const TmpNode& s = t.nodes[n];
+                    if (s.left < 0) continue;
+                    if (rec[n] >= 0) { q.push_back(s.left); q.push_back(s.right); continue; }      // already in the breadth-first top: look below it
+                    if (taken >= treelet) { frontier.push_back(n); continue; }
+                    rec[n] = nrec++; taken++;
+                    q.push_back(s.left); q.push_back(s.right);
+                }
+                for (size_t k = frontier.size(); k-- > 0;) roots.push_back(frontier[k]);
+            }
+        } else {
+            std::vector<int> st; st.push_back(0);
+            while (!st.empty()) {
+                int n = st.back(); st.pop_back();
+                const TmpNode& s = t.nodes[n];
+                if (s.left < 0) continue;
+                if (rec[n] < 0) rec[n] = nrec++;
+                st.push_back(s.right); st.push_back(s.left);
+            }
         }
     }
     out.top_records = (uint32_t)std::min<int>(nrec, (int)kTopRecords);

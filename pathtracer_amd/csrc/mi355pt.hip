@@ -67,7 +67,8 @@ struct DPaths {
                                     // when k_trace<0>(b) starts; the host stops enqueuing bounces once a bounce had no path left
     float4 *prep;         // [4 x cap] per path slot: the ray as k_prepare left it at its first mesh (see k_prepare)
     uint4 *lhit;          // [2 x cap] per visibility item: closest hit on the light's own Model (k_trace<2>), layout of `hit`
-    uint8_t  *vis;        // [2 x cap] 1 = blocked, per visibility item
+    uint8_t  *vis;        // [4 x cap bytes] per visibility item (2 per slot): 1 = blocked -- or, where k_trace<1> combines the results itself
+                          // (Params::fuse_connect), one word per slot: bits 0-1 = light sample (done, blocked), bits 2-3 = MIS sample
     uint32_t *work;       // [b] = next queue index to hand out in k_trace<closest> of bounce b (persistent refill)
     uint32_t *spill;      // per resident wave: kStackSize x 64 dwords, the part of a lane's stack below its LDS window
     uint32_t *spill_any;  // the same for k_trace<ANY>, which may run beside k_trace<closest> of the next bounce
@@ -75,7 +76,7 @@ struct DPaths {
                                 // [8..15] counting builds' diagnostics [16] vertices shaded [17] bilinear texture lookups [18] rays bounce 0's pre-pass finished in the current run
                                 // [19] visibility items that entered a visibility kernel (k_trace<1> / k_vis_connect)
 };
-struct Params { uint32_t seed, width, height, max_bounces, rr_start, stack_entries, node_lanes, owner_lanes, gen, use_prep, no_cull, ntop, setup_min; };
+struct Params { uint32_t seed, width, height, max_bounces, rr_start, stack_entries, node_lanes, owner_lanes, gen, use_prep, no_cull, ntop, setup_min, fuse_connect; };
 
 __device__ __forceinline__ F3 xyz(float4 v) { return f3(v.x, v.y, v.z); }
 __device__ __forceinline__ float4 f4(F3 v, float w) { return make_float4(v.x, v.y, v.z, w); }
@@ -378,6 +379,7 @@ __global__ void __launch_bounds__(kExtBlockMax) k_trace(DScene S, DPaths P, Para
     WorkCounters wc; wc.nodes = 0; wc.tris = 0; wc.top = 0;
     uint32_t state = LS_IDLE, slot = 0, rec = 0, sp = 0, sb = 0, lo = 0, owner = lane;
     uint32_t qidx = 0;                                                                     // closest: the ray's position in the bounce's queue (P.qhit)
+    uint32_t vdone = 0;                                                                    // any: this lane's item is decided (1 = visible, 2 = blocked), not yet reported
     F3 o = f3(0, 0, 0), inv = f3(0, 0, 0);
     float bt = kBig, pabs = 0.0f, bmarg = 0.0f;
     bool fastok = false;                                                                  // this lane's ray may take slab_pair_fast
@@ -395,6 +397,43 @@ __global__ void __launch_bounds__(kExtBlockMax) k_trace(DScene S, DPaths P, Para
             wr.p = xyz(sh[SHV_O]); wr.d = xyz(sh[(it & 1u) ? SHV_W2 : SHV_W1]);
         }
         if (S.num_recs > 0) wr = rec_ray(S, recl, 1u, 0u, wr);   // record 0 is cached in LDS; its level 0 is the root node
+    };
+    // ANY: reports the items decided since the last call.  Without fuse_connect that is the item's result byte for k_connect.  With it
+    // (scenes whose lights are all Planes: the MIS ray's light distance and pdf are in the shadow record already) the lane that
+    // decides a vertex's LAST item does k_connect's work on the spot -- power heuristic, `color += throughput * direct / selectPdf`
+    // (render.h:18-24, :87-105, :148) -- so the record is not read again by a second kernel.  A vertex with one item (nine in ten:
+    // the MIS ray mostly misses the light's plane in k_shade) needs no coordination; with two, each item ORs (done, blocked) into the
+    // vertex's word and the one that finds the other's done bit set combines.  Same expressions as k_connect, same bits.
+    auto report_vis = [&]() {
+        if (!ANY || vdone == 0u) return;
+        const bool blocked = vdone == 2u;
+        vdone = 0u;
+        if (!prm.fuse_connect) { P.vis[slot] = blocked ? 1 : 0; return; }
+        const uint32_t vs = slot >> 1, which = slot & 1u;
+        const float4* sh = P.sh + (size_t)vs * P.shv;
+        const float4 c1 = sh[SHV_C1];
+        const uint32_t fl = __float_as_uint(sh[SHV_W1].w) >> 28;
+        bool b0 = blocked, b1 = blocked;                          // results of the light sample / the MIS sample
+        if (fl == 3u) {
+            const uint32_t old = atomicOr((uint32_t*)P.vis + vs, (1u | (blocked ? 2u : 0u)) << (2u * which));
+            const uint32_t other = (old >> (2u * (which ^ 1u))) & 3u;
+            if (!(other & 1u)) return;                            // the other item is still being traced: its lane will combine
+            if (which) b0 = (other & 2u) != 0u; else b1 = (other & 2u) != 0u;
+        }
+        const float4 a2 = sh[SHV_A2], tb = sh[SHV_TB];
+        F3 direct = f3(0, 0, 0);
+        if ((fl & 1u) && !b0) direct = direct + xyz(c1);
+        if ((fl & 2u) && !b1) {
+            const float lightPdf = tb.w;
+            if (!(lightPdf <= 0.0f)) {
+                const float pb = c1.w;
+                const float w = (pb * pb) / (pb * pb + lightPdf * lightPdf);
+                direct = direct + xyz(a2) * w / pb;
+            }
+        }
+        F3 C = xyz(P.C[vs]);
+        C = C + xyz(tb) * (direct / a2.w);
+        P.C[vs] = f4(C, 0.0f);
     };
     uint32_t qh = 0, nq = 0;                                     // leaf queue (ring): head, count -- wave-uniform
     const uint32_t nwaves = gridDim.x * wpb;
@@ -432,6 +471,7 @@ __global__ void __launch_bounds__(kExtBlockMax) k_trace(DScene S, DPaths P, Para
         // every pass makes progress (a node step, a drained queue, a finished mesh or a new ray), so a wave needs a few
         // thousand passes; the guard turns a scheduling bug into an error code (stat[7]) instead of a hung GPU
         if (++guard > kExtendGuard) { if (lane == 0) atomicOr(&P.stat[7], 1ull); break; }
+        if (ANY && __ballot(vdone != 0u)) report_vis();          // items decided after the last drain
         // ================= setup: new rays for idle lanes, next object / mesh for lanes between meshes
         // The phase costs a wave the same for 3 lanes as for 40 (a chain of dependent loads: queue entry -> ray -> records): it is
         // skipped while fewer than `setup_min` lanes (32; MI355PT_SETUP_MIN, 1 = never skip) wait for it and the node loop has
@@ -443,6 +483,7 @@ __global__ void __launch_bounds__(kExtBlockMax) k_trace(DScene S, DPaths P, Para
             if (state == LS_SETUP) load_world(slot, wr);
             bool claimed = false;
             for (;;) {
+                if (ANY && __ballot(vdone != 0u)) report_vis();      // before `slot` is taken by the lane's next item
                 bool prepped = false; F3 p_o = f3(0, 0, 0), p_d = f3(0, 0, 0), p_inv = f3(0, 0, 0); uint32_t p_ref = 0, p_cnt = 0;
                 if (state == LS_IDLE && lane >= prm.owner_lanes) state = LS_DONE;     // test knob: these lanes only ever steal
                 const unsigned long long need = __ballot(state == LS_IDLE);
@@ -511,7 +552,7 @@ __global__ void __launch_bounds__(kExtBlockMax) k_trace(DScene S, DPaths P, Para
                                     F3 Pp;
                                     hit = L.kind == MI355PT_OBJ_PLANE ? plane_hit(lr.p, lr.d, SIDE_BOTH, lz, front, Pp) : sphere_hit(lr.p, lr.d, SIDE_BOTH, lz, front, Pp);
                                 }
-                                if (!hit || !front) { P.vis[slot] = 1; state = LS_IDLE; }
+                                if (!hit || !front) { vdone = 2u; state = LS_IDLE; }
                                 else bound = tmax < lz ? tmax : lz;              // (2) blocks iff z < tmax && z < lightZ
                             }
                         } else if (exhausted) state = LS_DONE;
@@ -552,7 +593,7 @@ __global__ void __launch_bounds__(kExtBlockMax) k_trace(DScene S, DPaths P, Para
                         const int side = ANY ? SIDE_FRONT : SIDE_BOTH;
                         const bool hit = kind == MI355PT_OBJ_PLANE ? plane_hit(lr.p, lr.d, side, t, front, Pp) : sphere_hit(lr.p, lr.d, side, t, front, Pp);
                         if (ANY) {
-                            if (hit && t < bound) { P.vis[slot] = 1; state = LS_IDLE; return true; }
+                            if (hit && t < bound) { vdone = 2u; state = LS_IDLE; return true; }
                         } else if (hit && t < best_t) { best_t = t; best_inst = (int)rii; best_mesh = -1; best_slot = 0; }
                         rec = nexti;
                         return false;
@@ -582,7 +623,7 @@ __global__ void __launch_bounds__(kExtBlockMax) k_trace(DScene S, DPaths P, Para
                 else if (state == LS_SETUP) {
                     for (;;) {
                         if (rec >= (OWN ? rec_end : (uint32_t)S.num_recs)) {
-                            if (ANY) P.vis[slot] = 0;
+                            if (ANY) vdone = 1u;
                             else if (OWN) P.lhit[slot] = make_uint4(__float_as_uint(best_t), (uint32_t)best_inst, (uint32_t)best_mesh, best_slot);
                             else { store_hit(P, slot, best_t, best_inst, best_mesh, best_slot); if (P.qhit) P.qhit[qidx] = best_inst; }
                             state = LS_IDLE;
@@ -766,7 +807,7 @@ __global__ void __launch_bounds__(kExtBlockMax) k_trace(DScene S, DPaths P, Para
         if (state == LS_WAIT && nwork[lane] == 0u) {                    // every lane that walked for this ray is done, the queue is empty
             const unsigned long long k = keyl[lane];
             if (ANY) {
-                if (k) { P.vis[slot] = 1; state = LS_IDLE; }
+                if (k) { vdone = 2u; state = LS_IDLE; }
                 else { rec++; state = LS_SETUP; }
             } else {
                 if (k != (hit_key(best_t, 0u) & ~1ull)) {
@@ -776,7 +817,7 @@ __global__ void __launch_bounds__(kExtBlockMax) k_trace(DScene S, DPaths P, Para
                 rec++; state = LS_SETUP;
             }
             if (state == LS_SETUP && rec >= (OWN ? rec_end : (uint32_t)S.num_recs)) {      // that was the last object: report now, the lane is idle
-                if (ANY) P.vis[slot] = 0;
+                if (ANY) vdone = 1u;
                 else if (OWN) P.lhit[slot] = make_uint4(__float_as_uint(best_t), (uint32_t)best_inst, (uint32_t)best_mesh, best_slot);
                 else { store_hit(P, slot, best_t, best_inst, best_mesh, best_slot); if (P.qhit) P.qhit[qidx] = best_inst; }
                 state = LS_IDLE;
@@ -1117,6 +1158,8 @@ k_shade(DScene S, DCamera cam, DPaths P, Params prm, uint32_t bounce, uint32_t n
                             sh[SHV_O] = f4(so, dist); sh[SHV_W1] = f4(wi1, __uint_as_float((uint32_t)li | (flags << 28))); sh[SHV_W2] = f4(wi2, mis_lz);
                             sh[SHV_C1] = f4(c1, pdf2); sh[SHV_A2] = f4(A2, selectPdf); sh[SHV_TB] = f4(T, mis_pdf);
                             if (!S.plane_lights_only) sh[SHV_HP] = f4(h.p, 0.0f);
+                            if (prm.fuse_connect && flags == 3u) ((uint32_t*)P.vis)[slot] = 0u;      // the two items meet in this word (k_trace<1>, report_vis)
+                            mis_blocked += (flags & 1u) + (flags >> 1);      // LightVisTest calls queued for a visibility kernel
                             shadow = true; vflags = flags;
                         }
                     }
@@ -1174,19 +1217,16 @@ k_shade(DScene S, DCamera cam, DPaths P, Params prm, uint32_t bounce, uint32_t n
 // done by k_trace<ANY>; this kernel combines their results.
 __global__ void __launch_bounds__(kBlock) k_connect(DScene S, DPaths P, uint32_t bounce) {
     const uint32_t n = (uint32_t)(P.svcounts[bounce] & 0xFFFFFFFFull);
-    unsigned long long rays = 0;
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {     // (the LightVisTest calls were counted when k_shade queued them)
         const uint32_t slot = P.squeue[i];
         const float4* sh = P.sh + (size_t)slot * P.shv;
         const float4 w1 = sh[SHV_W1], c1 = sh[SHV_C1], a2 = sh[SHV_A2];
         const uint32_t flags = __float_as_uint(w1.w) >> 28;
         F3 direct = f3(0, 0, 0);
         if (flags & 1u) {
-            rays++;
             if (!P.vis[2 * (size_t)slot]) direct = direct + xyz(c1);
         }
         if (flags & 2u) {
-            rays++;
             if (!P.vis[2 * (size_t)slot + 1]) {
                 // the light's hit point / normal of LightVisTest's first sweep (raytracer.cpp:67-97), for LightComponent::Pdf(wi)
                 // (scenes with Plane lights only: k_shade found both and left the pdf in the shadow record)
@@ -1217,7 +1257,6 @@ __global__ void __launch_bounds__(kBlock) k_connect(DScene S, DPaths P, uint32_t
         C = C + Tb * (direct / a2.w);
         P.C[slot] = f4(C, 0.0f);
     }
-    wave_add64(rays, &P.stat[1]);
 }
 
 // ---------------------------------------------------------------------- closest hit for scenes without Models
@@ -1284,7 +1323,7 @@ __global__ void __launch_bounds__(kBlock) k_vis_connect(DScene S, DPaths P, uint
         C = C + xyz(tb) * (direct / a2.w);
         P.C[slot] = f4(C, 0.0f);
     }
-    wave_add64(rays, &P.stat[1]);
+    (void)rays;                                                  // counted when k_shade queued the items
 }
 
 // ---------------------------------------------------------------------- resolve
@@ -1496,7 +1535,7 @@ struct mi355pt_render {
     struct Ev { hipEvent_t a, b; int kind; };
     std::vector<Ev> events; bool ev_open = false;
     double ms[4] = {0, 0, 0, 0}; uint64_t extend_launches = 0;
-    int grid = 2048, extend_grid = 768; TraceShape shape{1, 0, 0}; uint32_t stack_entries = 8, node_lanes = kNodeLanes, owner_lanes = 64, setup_min = 32; bool no_analytic_vis = false;
+    int grid = 2048, extend_grid = 768; TraceShape shape{1, 0, 0}; uint32_t stack_entries = 8, node_lanes = kNodeLanes, owner_lanes = 64, setup_min = 32; bool no_analytic_vis = false, no_fused_connect = false;
     ~mi355pt_render() {
         for (auto& e : events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
         for (hipEvent_t e : fork) (void)hipEventDestroy(e);
@@ -1884,6 +1923,10 @@ int mi355pt_render_create(mi355pt_scene* scene, const mi355pt_render_params* par
     // test knobs: results must not depend on either (tests/test_gpu_parity.py::test_traversal_schedule_*)
     if (const char* e = getenv("MI355PT_NODE_LANES")) r->node_lanes = (uint32_t)std::min(64, std::max(1, atoi(e)));
     r->no_analytic_vis = getenv("MI355PT_NO_ANALYTIC_VIS") != nullptr;
+    // Measured on C4 (profiles/r03e_*): the stage's exclusive time 44.2 -> 42.8 ms, the step 173.1 -> 173.8 ms -- the streaming k_connect
+    // at full occupancy moves its 47 GB of sectors at 6 TB/s, the same accesses inside the latency-bound traversal kernel cost it as
+    // much as the launch saved.  Off unless MI355PT_FUSED_CONNECT is set; the switch and its bit-identity test stay.
+    r->no_fused_connect = getenv("MI355PT_FUSED_CONNECT") == nullptr;
     if (const char* e = getenv("MI355PT_SETUP_MIN")) r->setup_min = (uint32_t)std::min(40, std::max(1, atoi(e)));
     if (const char* e = getenv("MI355PT_OWNER_LANES")) r->owner_lanes = (uint32_t)std::min(64, std::max(1, atoi(e)));
     r->count_work = getenv("MI355PT_COUNT_WORK") != nullptr;
@@ -1947,7 +1990,7 @@ hipError_t alloc_pool(mi355pt_render* r, size_t cap) {
     PT_GET(P.sh, cap * 16 * P.shv); PT_GET(P.queue[0], cap * 4); PT_GET(P.queue[1], cap * 4); PT_GET(P.squeue, cap * 4); PT_GET(P.vqueue, cap * 8);
     if (r->scene->model_lights) PT_GET(P.lhit, cap * 2 * sizeof(uint4));
     if (r->prep_bounces) PT_GET(P.prep, cap * 4 * sizeof(float4));
-    PT_GET(P.vis, cap * 2);
+    PT_GET(P.vis, cap * 4);
 #undef PT_GET
     P.cap = (uint32_t)cap;
     return hipSuccess;
@@ -2021,6 +2064,8 @@ int run_paths(mi355pt_render* r, uint32_t n, uint32_t jitter = 1, uint32_t only_
     const DScene& S = r->scene->d;
     Params prm{p.seed, p.width, p.height, p.max_bounces, p.rr_start, r->stack_entries, r->node_lanes, r->owner_lanes, ++r->gen, 0u, r->no_cull};
     prm.setup_min = r->setup_min;
+    // scenes with Models whose lights are all Planes: k_trace<1> combines a vertex's visibility results itself (report_vis), k_connect is not launched
+    prm.fuse_connect = (S.plane_lights_only && !r->scene->analytic_only && !r->no_fused_connect) ? 1u : 0u;
     HIP_TRY(hipMemsetAsync(r->ctr, 0, r->ctr_bytes, r->stream));     // counts, svcounts, work, vwork, lwork
     const int g = grid_for(r, n);
     const int ge = (int)std::max<size_t>(1, std::min<size_t>(((size_t)n + 63) / 64, (size_t)r->extend_grid));     // persistent: resident waves only
@@ -2103,7 +2148,7 @@ int run_paths(mi355pt_render* r, uint32_t n, uint32_t jitter = 1, uint32_t only_
                 launch_trace<2>(r->count_work, (size_t)ge, r->shape, vs, S, P, prm, b, n);
             }
             launch_trace<1>(r->count_work, (size_t)ge, r->shape, vs, S, P, prm, b, n);
-            hipLaunchKernelGGL(k_connect, dim3(g), dim3(kBlock), 0, vs, S, P, b);
+            if (!prm.fuse_connect) hipLaunchKernelGGL(k_connect, dim3(g), dim3(kBlock), 0, vs, S, P, b);
         }
         ev_end(r, vs);
         if (fork) { HIP_TRY(hipEventRecord(r->join[b], vs)); pending = true; last_fork = b; }

@@ -786,3 +786,33 @@ def test_black_environment_misses_same_results(built, name, monkeypatch):
         assert frac >= 0.999 and np.isfinite(a).all()
         pt.close_render()
     p2.close_render()
+
+
+@pytest.mark.parametrize("name", ["teapot_cornell", "grid_small", "textured_c2", "stress_layout"])
+def test_fused_connect_same_results(built, name, monkeypatch):
+    """MI355PT_FUSED_CONNECT (scenes with Models whose lights are all Planes): the lane of k_trace<1> that decides a vertex's last
+    visibility item does k_connect's combination on the spot (power heuristic, `color += throughput * direct / selectPdf`,
+    render.h:18-24, :148); a vertex with both a light-sample and a MIS item coordinates through one atomic word.  The default runs
+    k_connect as its own launch on the result bytes (the fusion measured no faster): same per-sample
+    radiance, accumulators and ray counts, bit for bit."""
+    s, orc, pt, w, h = built(name)
+    rng = np.random.default_rng(31)
+    pixel = rng.integers(0, w * h, 6000).astype(np.uint32)
+    sample = rng.integers(0, 64, 6000).astype(np.uint32)
+    a, _ = pt.sample_radiance(pixel, sample)
+    pt.Init(w, h); pt.step(4); pt.sync()
+    ma, ca = pt.read_accum()
+    sa = pt.stats()
+    monkeypatch.setenv("MI355PT_FUSED_CONNECT", "1")
+    p2 = PathTracer(pt.dscene)
+    monkeypatch.delenv("MI355PT_FUSED_CONNECT")
+    p2.Init(w, h)
+    b, _ = p2.sample_radiance(pixel, sample)
+    p2.Init(w, h); p2.step(4); p2.sync()
+    mb, cb = p2.read_accum()
+    sb = p2.stats()
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    assert np.array_equal(ma.view(np.uint32), mb.view(np.uint32)) and np.array_equal(ca, cb)
+    assert sa["closest_rays"] == sb["closest_rays"] and sa["shadow_rays"] == sb["shadow_rays"] and sa["shadow_rays_traversed"] == sb["shadow_rays_traversed"]
+    assert sa["shadow_rays_traversed"] > 0
+    p2.close_render()

@@ -17,7 +17,7 @@ import sqlite3
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-KERNEL_SOURCES = ["mi355pt.hip", "pt_device.h", "pt_shade.h", "pt_scene.h", "bvh_build.cpp", "bvh_build.h"]
+KERNEL_SOURCES = ["mi355pt.hip", "pt_device.h", "pt_shade.h", "pt_scene.h", "scene_flatten.hip", "bvh_build.cpp", "bvh_build.h"]
 
 
 def source_hash():
