@@ -125,6 +125,8 @@ def main():
             log("rehearsing the distributed paths with world size 1")
         dist.init_process_group("gloo")                     # control plane only; the data plane is RCCL inside the library
     device = local_rank if world > 1 else 0
+    if os.environ.get("BENCH_SHARE_DEVICE"):                # rehearsal on a one-GPU box: every rank on device 0 (RCCL refuses a communicator
+        device = 0                                          # with one GPU twice, so this run also exercises the gloo fallback of the read-out)
 
     from pathtracer_amd import DeviceScene, PathTracer, capi, distributed
     lib = capi.load_library()

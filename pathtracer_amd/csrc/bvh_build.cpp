@@ -311,6 +311,8 @@ void flatten_tree(const MeshTree& t, FlatMesh& out) {
         // steps then stay within K x 64 B.  Only the ORDER of the records changes; the tree, the slots and every result are the same.
         int treelet = 0;
         if (const char* e = getenv("MI355PT_RECORD_ORDER")) if (!strncmp(e, "treelet", 7)) treelet = std::max(2, std::min(64, atoi(e + 7)));
+        const char* order_env = getenv("MI355PT_RECORD_ORDER");
+        const bool by_area = order_env && !strcmp(order_env, "presa");
         if (treelet) {
             std::vector<int> roots; roots.push_back(0);           // treelet roots, depth-first over treelets
             std::vector<int> q;
@@ -338,7 +340,13 @@ void flatten_tree(const MeshTree& t, FlatMesh& out) {
                 const TmpNode& s = t.nodes[n];
                 if (s.left < 0) continue;
                 if (rec[n] < 0) rec[n] = nrec++;
-                st.push_back(s.right); st.push_back(s.left);
+                // "presa": the child with the larger surface area (the likelier descent) is the one that follows its parent
+                bool left_first = true;
+                if (by_area) {
+                    auto sa = [&](int c) { const float* b = t.nodes[c].bound; const float x = b[3] - b[0], y = b[4] - b[1], z = b[5] - b[2]; return x * y + y * z + z * x; };
+                    left_first = !(t.nodes[s.left].left < 0) && (t.nodes[s.right].left < 0 || sa(s.left) >= sa(s.right));
+                }
+                if (left_first) { st.push_back(s.right); st.push_back(s.left); } else { st.push_back(s.left); st.push_back(s.right); }
             }
         }
     }
