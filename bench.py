@@ -71,7 +71,7 @@ def cpu_baseline(scene, pt, args):
                 mi += 1
     orc = OracleScene(scene)
     threads = max(1, min(16, (os.cpu_count() or 2) - 1))
-    cw, ch = args.cpu_crop
+    cw, ch = min(args.cpu_crop[0], args.width), min(args.cpu_crop[1], args.height)
     x0, y0 = (args.width - cw) // 2, (args.height - ch) // 2
     prm = capi.make_params(args.width, args.height, seed=args.seed)
     t0 = time.perf_counter()
