@@ -139,7 +139,6 @@ struct mi355pt_group {
     mi355pt_render_params tmpl{};                     // the caller's parameters; every shard's are derived from them
     size_t npix = 0; uint32_t width = 0, height = 0;
     Combined out; bool combined_valid = false;
-    hipEvent_t e0 = nullptr, e1 = nullptr;
     double readout_ms = 0.0;
     std::mutex mu;
 };
@@ -152,8 +151,6 @@ int combine_group(mi355pt_group* g) {
     const int weighted = g->split == MI355PT_SPLIT_SAMPLE ? 1 : 0;
     const int grid = grid_of(g->npix);
     const auto t0 = std::chrono::steady_clock::now();
-    HIP_TRY(hipSetDevice(g->devs[0].device));
-    HIP_TRY(hipEventRecord(g->e0, g->devs[0].stream));
     // 1. every shard packs its accumulator; shards that share a device are added there (one stream per device keeps the order)
     for (auto& s : g->shards) {
         mi355pt_group::Dev& d = g->devs[s.dev_slot];
@@ -182,7 +179,6 @@ int combine_group(mi355pt_group* g) {
     HIP_TRY(hipSetDevice(d0.device));
     hipLaunchKernelGGL(k_unpack, dim3(grid), dim3(kBlock), 0, d0.stream, (const float4*)g->shards[d0.first_shard].pack, g->out.mean, g->out.cnt, g->out.rgb8, g->npix, weighted);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipEventRecord(g->e1, d0.stream));
     for (auto& d : g->devs) { HIP_TRY(hipSetDevice(d.device)); HIP_TRY(hipStreamSynchronize(d.stream)); }
     g->readout_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     g->combined_valid = true;
@@ -218,6 +214,12 @@ int make_renderers(mi355pt_group* g, const mi355pt_render_params* params) {
         HIP_TRY(hipSetDevice(g->devs[0].device));
         if (int rc = g->out.alloc(g->npix)) return rc;
     }
+    return MI355PT_OK;
+}
+
+// a reset that failed half-way leaves shards without a renderer: every later call says so instead of dereferencing one
+int ready(const mi355pt_group* g) {
+    for (auto& s : g->shards) if (!s.render) return fail(MI355PT_ERR_INVALID, "the group has no renderers (mi355pt_group_reset failed): reset it again or destroy it");
     return MI355PT_OK;
 }
 
@@ -265,7 +267,6 @@ int mi355pt_group_create(const mi355pt_scene_desc* desc, const int32_t* devices,
     if (int rc = mi355pt_scene_create_multi(desc, devlist.data(), (uint32_t)devlist.size(), scenes.data())) return cleanup(rc);
     for (auto& s : g->shards) s.scene = scenes[s.dev_slot];
     for (auto& d : g->devs) { if (hipSetDevice(d.device) != hipSuccess || hipStreamCreateWithFlags(&d.stream, hipStreamNonBlocking) != hipSuccess) return cleanup(fail(MI355PT_ERR_HIP, "hipStreamCreate failed")); }
-    if (hipSetDevice(g->devs[0].device) != hipSuccess || hipEventCreate(&g->e0) != hipSuccess || hipEventCreate(&g->e1) != hipSuccess) return cleanup(fail(MI355PT_ERR_HIP, "hipEventCreate failed"));
     if (int rc = make_renderers(g.get(), params)) return cleanup(rc);
     if (g->use_rccl) {
         std::vector<ncclComm_t> comms(devlist.size(), nullptr);
@@ -286,9 +287,6 @@ void mi355pt_group_destroy(mi355pt_group* g) {
         if (d.stream) (void)hipStreamDestroy(d.stream);
         if (d.first_shard >= 0 && g->shards[d.first_shard].scene) mi355pt_scene_destroy(g->shards[d.first_shard].scene);
     }
-    if (!g->devs.empty()) (void)hipSetDevice(g->devs[0].device);
-    if (g->e0) (void)hipEventDestroy(g->e0);
-    if (g->e1) (void)hipEventDestroy(g->e1);
     delete g;
 }
 
@@ -309,17 +307,20 @@ mi355pt_render* mi355pt_group_render(mi355pt_group* g, uint32_t shard) { return 
 int mi355pt_group_step(mi355pt_group* g, uint32_t spp) {
     if (!g) return fail(MI355PT_ERR_INVALID, "null group");
     std::lock_guard<std::mutex> lk(g->mu);
+    if (int rc = ready(g)) return rc;
     g->combined_valid = false;
     return for_each_shard(g, [&](size_t i) { return mi355pt_render_step(g->shards[i].render, spp); });
 }
 int mi355pt_group_sync(mi355pt_group* g) {
     if (!g) return fail(MI355PT_ERR_INVALID, "null group");
     std::lock_guard<std::mutex> lk(g->mu);
+    if (int rc = ready(g)) return rc;
     return for_each_shard(g, [&](size_t i) { return mi355pt_render_sync(g->shards[i].render); });
 }
 int mi355pt_group_read_rgb8(mi355pt_group* g, uint8_t* rgb) {
     if (!g || !rgb) return fail(MI355PT_ERR_INVALID, "null argument");
     std::lock_guard<std::mutex> lk(g->mu);
+    if (int rc = ready(g)) return rc;
     if (!g->out.mean) return mi355pt_render_read_rgb8(g->shards[0].render, rgb);      // one shard: its own frame, no arithmetic in between
     if (int rc = combine_group(g)) return rc;
     HIP_TRY(hipSetDevice(g->devs[0].device));
@@ -329,6 +330,7 @@ int mi355pt_group_read_rgb8(mi355pt_group* g, uint8_t* rgb) {
 int mi355pt_group_read_accum(mi355pt_group* g, float* mean_rgb, uint32_t* count) {
     if (!g) return fail(MI355PT_ERR_INVALID, "null argument");
     std::lock_guard<std::mutex> lk(g->mu);
+    if (int rc = ready(g)) return rc;
     if (!g->out.mean) return mi355pt_render_read_accum(g->shards[0].render, mean_rgb, count);
     if (int rc = combine_group(g)) return rc;
     HIP_TRY(hipSetDevice(g->devs[0].device));
@@ -339,6 +341,7 @@ int mi355pt_group_read_accum(mi355pt_group* g, float* mean_rgb, uint32_t* count)
 int mi355pt_group_stats(mi355pt_group* g, mi355pt_stats* st) {
     if (!g || !st) return fail(MI355PT_ERR_INVALID, "null argument");
     std::lock_guard<std::mutex> lk(g->mu);
+    if (int rc = ready(g)) return rc;
     memset(st, 0, sizeof(*st));
     for (auto& s : g->shards) {
         mi355pt_stats a;

@@ -194,3 +194,28 @@ def test_path_pool_is_sized_by_the_batch_and_survives_a_small_limit(monkeypatch)
     m, c = pt.read_accum()
     assert np.array_equal(c, cnt8) and np.array_equal(m.view(np.uint32), mean8.view(np.uint32))
     pt.close_render()
+
+
+def test_group_reset_keeps_the_scenes_and_forced_rccl_adds_shards_first():
+    """mi355pt_group_reset = PathTracer::Init on a live group: empty accumulators (also of another size), the uploaded scenes kept;
+    and two shards of one device under MI355PT_GROUP_FORCE_RCCL: packed, added on the device, then through ncclReduce."""
+    mk, w, h = SCENES["grid_small"]
+    s = mk(w, h)
+    g = PathTracerGroup(s, devices=[0, 0], split="sample", force_rccl=True)
+    g.Init(w, h)
+    g.step(2)
+    m1, c1 = g.read_accum()
+    assert (c1 == 4).all() and g.readout_ms() > 0.0
+    g.Init(w, h)                                   # reset: same size
+    m0, c0 = g.read_accum()
+    assert not c0.any() and not m0.any()
+    g.step(2)
+    m2, c2 = g.read_accum()
+    assert np.array_equal(c1, c2) and np.array_equal(m1.view(np.uint32), m2.view(np.uint32)), "a reset group renders what a fresh one renders"
+    img, mean, cnt, _ = _single(s, w, h, 4)
+    assert np.allclose(m2, mean, rtol=2e-6, atol=1e-7)
+    g.Init(w // 2, h // 2)                         # reset: another size
+    g.step(1)
+    m3, c3 = g.read_accum()
+    assert m3.shape == ((w // 2) * (h // 2), 3) and (c3 == 2).all()
+    g.close()
