@@ -108,6 +108,11 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
 
+    # stdout carries ONE JSON line.  Libraries underneath write banners to file descriptor 1 (gloo's "[Gloo] Rank ... connected", RCCL's
+    # version block): until the result is printed, descriptor 1 points at stderr.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -399,6 +404,8 @@ def main():
             out["roofline"], out["roofline_shade"] = trace, shade
     if rank == 0 and dist is None and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(scene, pt, args)
+    sys.stdout.flush()
+    os.dup2(real_stdout, 1)
     if rank == 0:
         print(json.dumps(out), flush=True)
     building.set()
