@@ -967,20 +967,20 @@ k_shade(DScene S, DCamera cam, DPaths P, Params prm, uint32_t bounce, uint32_t n
     extern __shared__ float4 tables[];
     if (TABLES) {                                                // (launched only with lds_tables != 0: a run-time choice would make the pointers generic)
         const uint32_t ni = (uint32_t)S.num_insts * (uint32_t)sizeof(DInst) / 16u, nn = ((uint32_t)S.num_nodes * (uint32_t)sizeof(DNodeXf) + 15u) / 16u;
-        const uint32_t nm = ((uint32_t)S.num_materials * (uint32_t)sizeof(mi355pt_material) + 15u) / 16u, nl = (uint32_t)S.num_lights * (uint32_t)sizeof(DLight) / 16u;
+        const uint32_t nm = ((uint32_t)S.num_materials * (uint32_t)sizeof(DMaterial) + 15u) / 16u, nl = (uint32_t)S.num_lights * (uint32_t)sizeof(DLight) / 16u;
         for (uint32_t k = threadIdx.x; k < ni; k += 64u) tables[k] = ((const float4*)S.insts)[k];
         for (uint32_t k = threadIdx.x; k < nn; k += 64u) tables[ni + k] = ((const float4*)S.nodes)[k];
         for (uint32_t k = threadIdx.x; k < nm; k += 64u) tables[ni + nn + k] = ((const float4*)S.materials)[k];
         for (uint32_t k = threadIdx.x; k < nl; k += 64u) tables[ni + nn + nm + k] = ((const float4*)S.lights)[k];
         __syncthreads();
         S.insts = (const DInst*)tables; S.nodes = (const DNodeXf*)(tables + ni);
-        S.materials = (const mi355pt_material*)(tables + ni + nn);
+        S.materials = (const DMaterial*)(tables + ni + nn);
         S.lights = (const DLight*)(tables + ni + nn + nm);
     }
     const float4* recl = nullptr; uint32_t nrc = 0;                  // VIS: the first walk records, behind the four tables
     if (TABLES && VIS) {
         const uint32_t ni = (uint32_t)S.num_insts * (uint32_t)sizeof(DInst) / 16u, nn = ((uint32_t)S.num_nodes * (uint32_t)sizeof(DNodeXf) + 15u) / 16u;
-        const uint32_t nm = ((uint32_t)S.num_materials * (uint32_t)sizeof(mi355pt_material) + 15u) / 16u, nl = (uint32_t)S.num_lights * (uint32_t)sizeof(DLight) / 16u;
+        const uint32_t nm = ((uint32_t)S.num_materials * (uint32_t)sizeof(DMaterial) + 15u) / 16u, nl = (uint32_t)S.num_lights * (uint32_t)sizeof(DLight) / 16u;
         nrc = (uint32_t)S.num_recs < kRecCache ? (uint32_t)S.num_recs : kRecCache;
         float4* dst = tables + ni + nn + nm + nl;
         for (uint32_t k = threadIdx.x; k < nrc * kRecStride; k += 64u) dst[k] = S.recs[k];
@@ -1449,7 +1449,7 @@ static_assert(sizeof(DInst) % 16 == 0 && sizeof(DLight) % 16 == 0, "k_shade copi
 uint32_t shade_table_bytes(const DScene& S, bool no_tables) {
     if (no_tables) return 0u;
     const size_t b = (size_t)S.num_insts * sizeof(DInst) + (((size_t)S.num_nodes * sizeof(DNodeXf) + 15) & ~(size_t)15) +
-                     (((size_t)S.num_materials * sizeof(mi355pt_material) + 15) & ~(size_t)15) + (size_t)S.num_lights * sizeof(DLight);
+                     (((size_t)S.num_materials * sizeof(DMaterial) + 15) & ~(size_t)15) + (size_t)S.num_lights * sizeof(DLight);
     return b <= 12288 ? (uint32_t)b : 0u;
 }
 
@@ -1483,7 +1483,7 @@ struct mi355pt_scene {
     std::shared_ptr<std::vector<ptb::MeshTree>> trees;     // the pointer trees, for mi355pt_scene_get_bvh (absent in a scene loaded from a file saved without them)
     DevBuf<DNodeXf> nodes; DevBuf<DInst> insts; DevBuf<DModel> models; DevBuf<DMesh> meshes;
     DevBuf<float4> bvh_nodes, tris, attrs, recs; DevBuf<uint32_t> faces; DevBuf<float> normals, uvw, tangents, bitangents;
-    DevBuf<mi355pt_material> materials; DevBuf<mi355pt_texmap> texmaps; DevBuf<DTexture> textures; DevBuf<DAtlas> atlases; DevBuf<int> mtl_atlas; DevBuf<DLight> lights; DevBuf<float> light_data;
+    DevBuf<DMaterial> materials; DevBuf<mi355pt_texmap> texmaps; DevBuf<DTexture> textures; DevBuf<DAtlas> atlases; DevBuf<int> mtl_atlas; DevBuf<DLight> lights; DevBuf<float> light_data;
     bool model_lights = false;        // some light sits on a Model: its own-object test is a BVH traversal (k_trace<2>)
     uint32_t mtl_kinds = 0;           // bit 0: some material is Disney, bit 1: some is Cook-Torrance ("standard")
     bool no_shade_tables = false;     // MI355PT_NO_SHADE_TABLES at scene creation: the same for every scene (the A/B and test switch)
@@ -1639,7 +1639,7 @@ int upload_scene(const pth::SceneView& v, int32_t device, std::shared_ptr<std::v
     const float4* attrs = v.ptr<float4>(pth::S_ATTRS, &n_attrs); const float4* recs = v.ptr<float4>(pth::S_RECS, &n_recs);
     const uint32_t* faces = v.ptr<uint32_t>(pth::S_FACES, &n_faces); const float* normals = v.ptr<float>(pth::S_NORMALS, &n_normals);
     const float* uvw = v.ptr<float>(pth::S_UVW, &n_uvw); const float* tangents = v.ptr<float>(pth::S_TANGENTS, &n_tan); const float* bitangents = v.ptr<float>(pth::S_BITANGENTS, &n_bit);
-    const mi355pt_material* materials = v.ptr<mi355pt_material>(pth::S_MATERIALS, &n_mtl); const mi355pt_texmap* texmaps = v.ptr<mi355pt_texmap>(pth::S_TEXMAPS, &n_tm);
+    const DMaterial* materials = v.ptr<DMaterial>(pth::S_MATERIALS, &n_mtl); const mi355pt_texmap* texmaps = v.ptr<mi355pt_texmap>(pth::S_TEXMAPS, &n_tm);
     const DTexture* textures = v.ptr<DTexture>(pth::S_TEXTURES, &n_tex); const DAtlas* atlases = v.ptr<DAtlas>(pth::S_ATLASES, &n_atl);
     const int* mtl_atlas = v.ptr<int>(pth::S_MTL_ATLAS, &n_ma); const DLight* lights = v.ptr<DLight>(pth::S_LIGHTS, &n_li); const float* light_data = v.ptr<float>(pth::S_LIGHT_DATA, &n_ld);
     if (!nodes || n_nodes == 0) return fail(MI355PT_ERR_INVALID, "scene without nodes");

@@ -64,7 +64,7 @@ struct HostScene {
     std::vector<ptd::DNodeXf> nodes; std::vector<ptd::DInst> insts; std::vector<ptd::DModel> models; std::vector<ptd::DMesh> meshes;
     std::vector<float4> bvh_nodes, tris, attrs, recs;
     std::vector<uint32_t> faces; std::vector<float> normals, uvw, tangents, bitangents;
-    std::vector<mi355pt_material> materials; std::vector<mi355pt_texmap> texmaps;
+    std::vector<ptd::DMaterial> materials; std::vector<mi355pt_texmap> texmaps;
     std::vector<ptd::DTexture> textures;                     // data = nullptr here; the texels are in tex_pixels[i]
     std::vector<std::vector<unsigned char>> tex_pixels;       // RGBA8 (uchar4) or RGBA32F (float4) as the kernels read them
     std::vector<ptd::DAtlas> atlases; std::vector<std::vector<uint2>> atlas_pixels; std::vector<int> mtl_atlas;

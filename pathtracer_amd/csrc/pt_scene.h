@@ -27,6 +27,13 @@ struct DMesh {
     uint32_t vert_base;              // offset (in vertices) into normals / uvw
     uint32_t has_tangents, pad;
 };
+// A material as the kernels read it: the ABI's parameters plus what depends on them alone.  The clearcoat lobe's GTR1 widths and
+// their logarithms (DisneyEval / DisneyPdf, disneyBrdf.h:141,196) are functions of clearcoatGloss only -- untextured -- so they are
+// taken once per material on the host, with libm's logf as the reference takes them, instead of two fp64 logarithms per vertex.
+struct DMaterial : mi355pt_material {
+    float a_eval, log_eval, a_pdf, log_pdf;
+    float pad[3];                // 112 B: whole 16-B pieces for k_shade's copy to LDS
+};
 struct DTexture { int kind, width, height, pad; const void* data; float c1[3], c2[3]; };
 // A material whose four maps (albedo, normal, roughness, metalness) are 8-bit images of one size under one texture
 // transform gets a fused copy of them, 8 B per texel: albedo RGB, normal RGB, roughness R, metalness R (the scalar maps
@@ -65,7 +72,7 @@ struct DScene {
     const float*    uvw;             // 3 per vertex
     const float*    tangents;        // 3 per face (indexed face_base + faceId)
     const float*    bitangents;
-    const mi355pt_material* materials; int num_materials;
+    const DMaterial* materials; int num_materials;
     const mi355pt_texmap*   texmaps;
     const DTexture* textures;
     const int*      mtl_atlas;       // per material: index into atlases, -1 = none; nullptr when the scene has no atlas

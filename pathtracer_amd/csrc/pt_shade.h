@@ -310,7 +310,10 @@ PT_DEV float smith_ggx(float NdotV, float a) {
     return 1.0f / (NdotV + sqrtf(a2 + b - a2 * b));
 }
 PT_DEV float schlick(float u) {
-    const float m = dclamp((float)(1.0 - (double)u), 0.0f, 1.0f);
+    // The reference's `1.0 - u` is a double subtraction rounded to float (disneyBrdf.h:69).  For a float u that is the float
+    // subtraction: the exact difference fits a double whenever |u| >= 2^-29, and below that it lies strictly inside (1 - 2^-29, 1 + 2^-29),
+    // where no midpoint of two floats is -- rounding once or twice gives the same float.
+    const float m = dclamp(1.0f - u, 0.0f, 1.0f);
     const float m2 = m * m;
     return m2 * m2 * m;
 }
@@ -336,8 +339,7 @@ PT_DEV void disney_finish(Disney& s) {      // Clamp + InitCSW (disneyBrdf.h:108
     const F3 c_spec0 = mixv((1.0f - s.specular * 0.3f) * mixv(f3(1, 1, 1), c_tint, s.specularTint), cd, s.metallic);
     const float cs_lum = dot(c_spec0, f3(0.3f, 0.6f, 0.1f));
     s.csw = cs_lum / (cs_lum + (1.0f - s.metallic) * cd_lum);
-    s.a_eval = mixf(0.1f, 0.001f, s.clearcoatGloss); s.log_eval = a_logf(s.a_eval * s.a_eval);
-    s.a_pdf = mixf(0.1f, 0.001f, s.a_eval); s.log_pdf = a_logf(s.a_pdf * s.a_pdf);
+    // (a_eval, log_eval, a_pdf, log_pdf: functions of the material's clearcoatGloss alone, set by mat_prepare from DMaterial)
     // DisneyEval's own c_spec0 (0.3 * specular, where InitCSW has 1 - 0.3 * specular: disneyBrdf.h:127 vs :166) and c_sheen
     s.c_spec0 = mixv(s.specular * 0.3f * mixv(f3(1, 1, 1), c_tint, s.specularTint), cd, s.metallic);
     s.c_sheen = mixv(f3(1, 1, 1), c_tint, s.sheenTint);
@@ -493,7 +495,7 @@ struct MatCtx {
 // ATLAS: the scene has material atlases (DScene::mtl_atlas); instances for scenes without one do not carry that code.
 template <int KIND = -1, bool ATLAS = true>
 PT_DEV void mat_prepare(const DScene& S, const Surf& h, MatCtx& m) {
-    const mi355pt_material& mt = S.materials[h.mtl];
+    const DMaterial& mt = S.materials[h.mtl];
     m.kind = KIND >= 0 ? KIND : mt.kind;
     F3 N = h.N; N = N / len(N);
     m.Ngeo = N;
@@ -525,6 +527,7 @@ PT_DEV void mat_prepare(const DScene& S, const Surf& h, MatCtx& m) {
         m.d.metallic = metal;
         m.d.clearcoat = mt.clearcoat; m.d.clearcoatGloss = mt.clearcoat_gloss; m.d.sheen = mt.sheen; m.d.sheenTint = mt.sheen_tint;
         m.d.specular = mt.specular; m.d.specularTint = mt.specular_tint; m.d.subsurface = mt.subsurface;
+        m.d.a_eval = mt.a_eval; m.d.log_eval = mt.log_eval; m.d.a_pdf = mt.a_pdf; m.d.log_pdf = mt.log_pdf;
         disney_finish(m.d);
         const int li = h.light;
         if (li >= 0) m.emission = ld3(S.lights[li].intensity);      // disneyMaterial.h:193-198

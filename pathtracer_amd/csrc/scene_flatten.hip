@@ -31,7 +31,7 @@ const char* last_error() { return g_err.c_str(); }
 
 uint32_t layout_hash() {
     const uint32_t parts[] = {(uint32_t)sizeof(DNodeXf), (uint32_t)sizeof(DInst), (uint32_t)sizeof(DModel), (uint32_t)sizeof(DMesh), (uint32_t)sizeof(DTexture),
-                              (uint32_t)sizeof(DAtlas), (uint32_t)sizeof(DLight), (uint32_t)kRecStride, (uint32_t)sizeof(mi355pt_material), (uint32_t)sizeof(mi355pt_texmap),
+                              (uint32_t)sizeof(DAtlas), (uint32_t)sizeof(DLight), (uint32_t)kRecStride, (uint32_t)sizeof(DMaterial), (uint32_t)sizeof(mi355pt_texmap),
                               (uint32_t)sizeof(ptb::TmpNode), (uint32_t)ptb::kMaxLeaf, (uint32_t)ptb::kTopRecords, (uint32_t)sizeof(Header)};
     uint32_t h = 2166136261u;
     for (uint32_t p : parts) { h ^= p; h *= 16777619u; }
@@ -266,9 +266,19 @@ int flatten_scene(const mi355pt_scene_desc* desc, HostScene& hs) {
     H.plane_lights_only = 1;
     for (const DLight& L : lights) if (L.kind != MI355PT_OBJ_PLANE) H.plane_lights_only = 0;
     // ---- materials / textures
-    hs.materials.assign(desc->materials, desc->materials + desc->num_materials);
+    hs.materials.assign(desc->num_materials, DMaterial{});
+    for (uint32_t i = 0; i < desc->num_materials; i++) {
+        DMaterial& d = hs.materials[i];
+        static_cast<mi355pt_material&>(d) = desc->materials[i];
+        // Clamp (disneyBrdf.h:108-120) of clearcoatGloss, then the two GTR1 widths: DisneyEval mixes by the gloss (:196), DisneyPdf mixes
+        // again by that width (:141, the reference's double mix); log(a * a) as GTR1 takes it (:60-66), libm's logf like the reference
+        float g = d.clearcoat_gloss; g = g > 0.999f ? 0.999f : g; g = g < 0.001f ? 0.001f : g;
+        d.a_eval = 0.1f * (1.0f - g) + 0.001f * g; d.log_eval = logf(d.a_eval * d.a_eval);
+        d.a_pdf = 0.1f * (1.0f - d.a_eval) + 0.001f * d.a_eval; d.log_pdf = logf(d.a_pdf * d.a_pdf);
+        d.pad[0] = d.pad[1] = d.pad[2] = 0.0f;
+    }
     hs.texmaps.assign(desc->texmaps, desc->texmaps + desc->num_texmaps);
-    std::vector<mi355pt_material>& materials = hs.materials; std::vector<mi355pt_texmap>& texmaps = hs.texmaps;
+    std::vector<DMaterial>& materials = hs.materials; std::vector<mi355pt_texmap>& texmaps = hs.texmaps;
     H.mtl_kinds = 0;
     for (auto& m : materials) {
         if (m.kind != MI355PT_MTL_DISNEY && m.kind != MI355PT_MTL_STANDARD) return fail(MI355PT_ERR_UNSUPPORTED, "unknown material kind");
