@@ -4,7 +4,7 @@
 Workload (BASELINE.json configs[3], the 10M-triangle scene the metric is quoted on): the
 instanced teapot_lowpoly grid baked into one 10 036 800-triangle mesh / one BVH, 3840x2160,
 Disney rough material + one rectangular area light, primary + secondary rays, 30 bounces max.
-One "step" = one batch of --spp-per-step (default 32: half of the configuration's 64 spp, 0.34 s -- the reference GUI's poll period) samples per pixel of the whole frame through the full hot path
+One "step" = one batch of --spp-per-step (default 64: the configuration's 64 spp as ONE batch, 0.65 s, 151 GB of path pool) samples per pixel of the whole frame through the full hot path
 (init -> {extend, shade, connect} x bounces -> resolve) with the scene resident in HBM.
 
 N GPUs: one process per GPU (torchrun; torch.distributed with the gloo backend is the control plane only: rendezvous, barriers,
@@ -73,7 +73,7 @@ def cpu_baseline(scene, pt, args):
     threads = max(1, min(16, (os.cpu_count() or 2) - 1))
     cw, ch = min(args.cpu_crop[0], args.width), min(args.cpu_crop[1], args.height)
     x0, y0 = (args.width - cw) // 2, (args.height - ch) // 2
-    prm = capi.make_params(args.width, args.height, seed=args.seed)
+    prm = capi.make_params(args.width, args.height, seed=args.seed, max_bounces=args.max_bounces)
     t0 = time.perf_counter()
     _, _, _, st = orc.render(prm, args.cpu_spp, rect=(x0, y0, x0 + cw, y0 + ch), threads=threads)
     dt = time.perf_counter() - t0
@@ -97,8 +97,10 @@ def main():
     ap.add_argument("--cpu-crop", type=int, nargs=2, default=[3840, 2160])
     ap.add_argument("--cpu-spp", type=int, default=3)
     ap.add_argument("--split", choices=["sample", "tile"], default="sample")
-    ap.add_argument("--spp-per-step", type=int, default=32,
+    ap.add_argument("--spp-per-step", type=int, default=64,
                     help="samples per pixel in one step = one batch through the hot path (the late bounces' fixed cost is paid once per batch)")
+    ap.add_argument("--max-bounces", type=int, default=30,
+                    help="IndirectLightBounceCount of the reference (config.h: 30); 1 = primary rays and their light connections only")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
                     help="weak: every GPU renders --spp-per-step samples per step (of every pixel / of its tiles x N); strong: the step's --spp-per-step samples are divided among the GPUs")
     ap.add_argument("--total-spp", type=int, default=0, help="strong scaling: total samples per pixel of the job (sets --steps = total / spp-per-step), e.g. C3's 1024")
@@ -193,12 +195,12 @@ def main():
     strong = args.scaling == "strong"
     if args.split == "tile":
         ts, toff, tstride = distributed.rank_tile_split(rank, world, 64)
-        pt = PathTracer(dscene, device=device, seed=args.seed, tile_size=ts, tile_offset=toff, tile_stride=tstride)
+        pt = PathTracer(dscene, device=device, seed=args.seed, max_bounces=args.max_bounces, tile_size=ts, tile_offset=toff, tile_stride=tstride)
         # a rank owns 1/N of the pixels: weak = N samples of each keep the per-GPU work fixed; strong = the step's samples of its tiles
         spp_step = args.spp_per_step if strong else world * args.spp_per_step
     else:
         off, stride = distributed.rank_sample_split(rank, world)
-        pt = PathTracer(dscene, device=device, seed=args.seed, sample_offset=off, sample_stride=stride)
+        pt = PathTracer(dscene, device=device, seed=args.seed, max_bounces=args.max_bounces, sample_offset=off, sample_stride=stride)
         spp_step = args.spp_per_step // world if strong else args.spp_per_step
     pt.Init(args.width, args.height)
     phase[0] = "running"
@@ -206,7 +208,7 @@ def main():
         log(f"scene + BVH + upload: {time.perf_counter() - t0:.1f} s  {host}")
 
     # ---- the read-out of N > 1: a communicator inside the library (RCCL); every rank must have one, or all take the gloo path
-    comm, readout = None, None
+    comm, readout, comm_hung = None, None, False
     if dist is not None:
         readout = "gloo"
         if args.readout == "library":
@@ -219,9 +221,19 @@ def main():
             ok = int(t[-1])
             if ok:
                 uid = (C.c_uint8 * capi.COMM_ID_BYTES)(*[int(x) for x in t[:-1]])
-                h = C.c_void_p()
-                if lib.mi355pt_comm_create(uid, rank, world, device, C.byref(h)) != 0:
-                    log(f"rank {rank}: mi355pt_comm_create failed:", lib.mi355pt_last_error().decode()); ok = 0
+                # the rendezvous of N processes blocks until all have arrived: on its own thread with a limit, so that a rank that
+                # never arrives ends in the fallback (and this process in os._exit at the end) instead of in the driver's timeout
+                h, res = C.c_void_p(), {}
+
+                def create():
+                    rc = lib.mi355pt_comm_create(uid, rank, world, device, C.byref(h))
+                    res["rc"], res["msg"] = rc, (lib.mi355pt_last_error().decode() if rc else "")
+                th = threading.Thread(target=create, daemon=True)
+                th.start(); th.join(float(os.environ.get("BENCH_COMM_TIMEOUT", "120")))
+                if th.is_alive():
+                    log(f"rank {rank}: mi355pt_comm_create has not returned; giving it up"); ok = 0; comm_hung = True
+                elif res["rc"] != 0:
+                    log(f"rank {rank}: mi355pt_comm_create failed:", res["msg"]); ok = 0
                 else:
                     comm = h
             t = torch.tensor([ok], dtype=torch.int32)
@@ -300,7 +312,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": workload, "triangles": tris,
-                       "resolution": [args.width, args.height], "spp_per_step": args.spp_per_step, "max_bounces": 30,
+                       "resolution": [args.width, args.height], "spp_per_step": args.spp_per_step, "max_bounces": args.max_bounces,
                        "spp_per_step_per_gpu": spp_step,
                        "split": ("sample index g, g+N, ... per GPU" if args.split == "sample" else "64x64 image tiles k % N == g")
                                 + "; one RCCL reduce at the end",
@@ -415,6 +427,9 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    if comm_hung:                   # a thread of this process is still inside the rendezvous: leave without waiting for it
+        sys.stderr.flush()
+        os._exit(0)
 
 
 if __name__ == "__main__":

@@ -1830,10 +1830,10 @@ int mi355pt_render_create(mi355pt_scene* scene, const mi355pt_render_params* par
     // Path slots of one chunk.  Sixteen samples of a 4K frame fit (278 or 294 B per slot, 37.3 or 39.5 GB of the 288): a step of several samples runs them as ONE batch, and the fixed
     // cost of a batch -- above all the ~20 late bounces that a few thousand Russian-roulette survivors drag out at one ray's
     // latency each (3.4 of 18 ms for a single 4K sample of C4, profiles/r02b_timeline.txt) -- is paid once per batch.
-    // C4, samples per batch 1 / 8 / 16 / 32 / 64 with round 3's kernels: 2 5xx / 3 3xx / 3 985 / 4 077 / 4 197 Mrays/s (gpurun_out/r03g).
+    // C4, samples per batch 16 / 32 / 64 with round 3's kernels: 3 985 / 4 154 / 4 270 Mrays/s (gpurun_out/r03g, r03v).
     // That is the pool's LIMIT (MI355PT_MAX_PATHS); the pool itself is allocated by the first call that needs it, for the
-    // batch that call asks for (ensure_pool): a renderer stepped one sample at a time holds one frame of slots, not sixteen.
-    size_t cap = 268435456;                                   // 2^28 slots = 32 samples of a 4K frame, 75.7 GB -- only for a caller that asks for such a batch
+    // batch that call asks for (ensure_pool): a renderer stepped one sample at a time holds one frame of slots, not sixty-four.
+    size_t cap = 536870912;                                   // 2^29 slots = 64 samples of a 4K frame, 151 GB of the 288 -- only for a caller that asks for such a batch
     if (const char* e = getenv("MI355PT_MAX_PATHS")) cap = std::max<size_t>(65536, strtoull(e, nullptr, 10));
     cap = std::min(cap, std::max<size_t>(npix, 65536) * 64);
     cap = (cap + 63) & ~(size_t)63;

@@ -372,7 +372,7 @@ int mi355pt_comm_create(const uint8_t id[MI355PT_COMM_ID_BYTES], int32_t rank, i
     *out = nullptr;
     if (int rc = need_rccl()) return rc;
     HIP_TRY(hipSetDevice(device));
-    std::unique_ptr<mi355pt_comm> c(new mi355pt_comm());
+    std::unique_ptr<mi355pt_comm, void (*)(mi355pt_comm*)> c(new mi355pt_comm(), mi355pt_comm_destroy);     // a failure below releases what exists
     c->rank = rank; c->nranks = nranks; c->device = device;
     ncclUniqueId u; memcpy(u.internal, id, NCCL_UNIQUE_ID_BYTES);
     NCCL_TRY(rccl()->CommInitRank(&c->comm, nranks, u, rank));

@@ -1,13 +1,13 @@
 #!/bin/bash
 # Round measurement on the GPU box: bench line, kernel-trace stats, the two HBM-traffic PMC passes and one SQ pass
 # (VALU utilisation / wait share / occupancy), for one workload.
-#   bash tools/gpu_measure.sh <tag> [workload c1..c5 = c4] [samples per step = 32] [triangles of c5] [phase all|bench|pmc]     (through gpurun, from the repo root)
+#   bash tools/gpu_measure.sh <tag> [workload c1..c5 = c4] [samples per step = 64] [triangles of c5] [phase all|bench|pmc]     (through gpurun, from the repo root)
 # BENCH_ARGS in the environment is appended to the bench command lines (e.g. "--cpu-crop 128 128 --cpu-spp 1" for the 100 M-triangle soup);
 # the phases exist because five runs of a scene that takes 100 s to build do not fit one gpurun call.
 # Afterwards, here: tools/rocpd_summary.py + tools/pmc_traffic.py turn the databases into the files kept under profiles/.
 # Every profiler pass runs the program itself behind `--` and only one counter block per pass (rocprofv3 does not split passes).
 set -o pipefail
-tag=${1:-r03}; wl=${2:-c4}; spp=${3:-32}; tris=${4:-100000000}; phase=${5:-all}
+tag=${1:-r03}; wl=${2:-c4}; spp=${3:-64}; tris=${4:-100000000}; phase=${5:-all}
 out=$PWD/gpurun_out/$tag
 mkdir -p $out
 export TMPDIR=/tmp
