@@ -7,12 +7,13 @@ w, h = 3840, 2160
 nx, ny = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (205, 204)
 ds = DeviceScene(scenes.grid_c4(nx, ny, w, h))
 prev = None
-for mb in (1, 2, 3, 4, 6):
+spp = int(os.environ.get("DIAG_SPP", "1"))      # samples per batch (1 = latency-bound launches; 16+ = the bench's regime)
+for mb in (1, 2, 3, 4, 6, 30):
     pt = PathTracer(ds, max_bounces=mb)
     pt.Init(w, h)
-    pt.render(1)
-    pt.reset_stats(); pt.set_profiling(True, False); pt.render(1); t = pt.stats()
-    pt.reset_stats(); pt.set_profiling(False, True); pt.render(1); c = pt.stats()
+    pt.render(spp)
+    pt.reset_stats(); pt.set_overlap(1 << 30); pt.set_profiling(2, False); pt.render(spp); t = pt.stats(); pt.set_overlap(0)
+    pt.reset_stats(); pt.set_profiling(False, True); pt.render(spp); c = pt.stats()
     dbg = c["debug"]
     cur = dict(cs=dbg[0], cn=dbg[1], cd=dbg[2], cr=dbg[3], nit=dbg[4], nact=dbg[5], dit=dbg[6] >> 32, dact=dbg[6] & 0xFFFFFFFF, rays=c["closest_rays"], nodes=c["bvh_node_visits"], tris=c["bvh_tri_tests"], ext=t["extend_ms"], sh=t["shade_ms"], co=t["connect_ms"],
                srays=c["shadow_rays"], snodes=c["shadow_node_visits"], stris=c["shadow_tri_tests"])
