@@ -269,7 +269,28 @@ def main():
     for _ in range(args.warmup):
         pt.step(spp_step)
     pt.sync()
-    if dist is not None and args.warmup > 0:     # the read-out is part of the job: warm it up too (RCCL channels, buffers)
+    if readout == "rccl-in-library":
+        # The read-out is part of the job: warm it up too (RCCL channels, buffers) -- on its own thread with a limit, because a
+        # collective that one rank never enters blocks the others for good.  Every rank must have come back, or all of them
+        # take the host-staged path (which reads the accumulators on the renderer's own stream, not the communicator's).
+        res = {}
+
+        def probe():
+            try:
+                read_out(); res["ok"] = 1
+            except Exception as e:      # noqa: BLE001 -- any failure of the probe means "fall back"
+                res["ok"] = 0; log(f"rank {rank}: read-out through the library failed: {e}")
+        th = threading.Thread(target=probe, daemon=True)
+        th.start(); th.join(float(os.environ.get("BENCH_COMM_TIMEOUT", "120")))
+        if th.is_alive():
+            log(f"rank {rank}: the RCCL reduce has not returned; giving it up"); comm_hung = True
+        t = torch.tensor([0 if th.is_alive() else res.get("ok", 0)], dtype=torch.int32)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        if not int(t[0]):
+            readout = "gloo"
+            if rank == 0:
+                log("falling back to the host-staged gloo reduce")
+    elif dist is not None and args.warmup > 0:
         read_out()
     pt.reset_stats()
     pt.set_profiling(events=1, count_work=False)        # HIP events around every launch of the dominant kernel, on its stream
@@ -422,7 +443,7 @@ def main():
         print(json.dumps(out), flush=True)
     building.set()
     pt.close_render()
-    if comm is not None:
+    if comm is not None and not comm_hung:
         lib.mi355pt_comm_destroy(comm)
     if dist is not None:
         dist.barrier()
