@@ -137,8 +137,12 @@ def main():
 
     from pathtracer_amd import DeviceScene, PathTracer, capi, distributed
     lib = capi.load_library()
-    if lib.mi355pt_device_count() < 1:
+    ndev = lib.mi355pt_device_count()
+    if ndev < 1:
         raise SystemExit("bench.py needs a gfx950 device; there is no CPU fallback")
+    if device >= ndev:                                      # a launcher that shows each rank its own GPU only (HIP_VISIBLE_DEVICES per rank)
+        log(f"rank {rank}: LOCAL_RANK {local_rank} but {ndev} visible device(s); using device {device % ndev}")
+        device %= ndev
     if args.scaling == "strong":
         if args.total_spp:
             args.steps = max(1, args.total_spp // args.spp_per_step)
