@@ -1,11 +1,11 @@
 #!/bin/bash
 # Bench lines of the other BASELINE configurations (parity-test cases, recorded for DESIGN.md / BASELINE.md section 4), each with
 # the CPU port timed beside it on a bounded sample.  A step = one batch of as many samples as the path pool holds for the image
-# (C1: all 64 spp of the configuration).  Usage: bash tools/bench_configs.sh [tag]
+# (C1: all 64 spp of the configuration; C2: all 256; C3, like C4: 64).  Usage: bash tools/bench_configs.sh [tag]
 set -o pipefail
 tag=${1:-cfg}
 mkdir -p gpurun_out/$tag
-for c in "c1 512 512 64 512 512 16" "c2 1920 1080 32 960 540 1" "c3 3840 2160 32 3840 2160 2"; do
+for c in "c1 512 512 64 512 512 16" "c2 1920 1080 256 960 540 1" "c3 3840 2160 64 3840 2160 2"; do
   set -- $c
   timeout -k 10 400 python3 bench.py --workload $1 --width $2 --height $3 --spp-per-step $4 --cpu-crop $5 $6 --cpu-spp $7 --steps 4 > gpurun_out/$tag/bench_$1.json 2>/dev/null || exit 1
   python3 - "$1" "$tag" <<'PY'
