@@ -116,6 +116,24 @@ __device__ __forceinline__ uint32_t xcd_block(uint32_t b, uint32_t nb) {
     return (b & 7u) * per + (b >> 3);
 }
 
+// Rays that cannot hit a triangle but that no slab test rejects.  A path that goes on from a degenerate BRDF sample can carry
+//   * a ZERO direction: 1/d = +inf in every axis, (min - o) * inf = -inf for both planes of every slab, and `tmin > tymax`
+//     compares -inf > -inf -- false: the line "hits" every box (bvh.h:88-129), while d . n = 0 fails `|d . n| > FLT_EPSILON`
+//     for every triangle (model.h:236-240; a NaN d . n gives a NaN distance, next case);
+//   * a NaN in its origin or direction: every component of the mesh-space ray is NaN after the node transforms, NaN compares
+//     fall through every slab test, and t = (v0 . n - o . n) / (d . n) is NaN for every triangle, which is never better than
+//     the best so far (`z < best.z`, model.cpp:25-60; tri_closest_key's key compare; `t < bound` in tri_any_front).
+// The reference -- and the literal walk here -- visits every node and tests every triangle of the mesh for such a ray: 10 M
+// nodes on ONE wave, 0.2 s in which the rest of the GPU idles.  They are rare and deterministic: six 32-sample steps in the
+// first 1 600 samples of C4 took 530 instead of 334 ms, each for one bounce-2 ray with d = (0, 0, 0) (tools/step_times.py,
+// tools/diag_nonfinite.py); a 25-step bench run is 10 % slower for them.  The walk of such a ray skips the meshes (analytic
+// objects are still tested literally: a Plane can be hit by a ray with one NaN component).  Same hits, same images;
+// MI355PT_WALK_DEAD_RAYS=1 restores the literal walk (test_dead_rays_skip_meshes_same_results).
+__device__ __forceinline__ bool ray_cannot_hit_triangles(F3 p, F3 d) {
+    const bool has_nan = !(p.x == p.x && p.y == p.y && p.z == p.z && d.x == d.x && d.y == d.y && d.z == d.z);
+    return has_nan || (d.x == 0.0f && d.y == 0.0f && d.z == 0.0f);
+}
+
 // One ray of k_prepare (below): the object walk up to the first mesh `wr` must traverse.
 // Returns true when the ray was finished here (no mesh in its way).
 __device__ __forceinline__ bool prepare_ray(const DScene& S, const DPaths& P, uint32_t slot, uint32_t qidx, Ray wr) {
@@ -152,6 +170,7 @@ __device__ __forceinline__ bool prepare_ray(const DScene& S, const DPaths& P, ui
         bool go = in_mesh;
         if (go && rc == kInternal) go = in_root;
         if (go && rc == 0u) go = false;
+        if (go && S.skip_dead_rays && ray_cannot_hit_triangles(lr.p, lr.d)) go = false;
         if (!go) { rec++; continue; }
         found = true; o = lr.p; d = lr.d; inv = linv; root_ref = __float_as_uint(h1.z); root_cnt = rc;
         break;
@@ -615,6 +634,7 @@ __global__ void __launch_bounds__(kExtBlockMax) k_trace(DScene S, DPaths P, Para
                     bool go = in_mesh;
                     if (go && root_cnt == kInternal) { if (COUNT) wc.nodes++; go = in_root; }
                     if (go && root_cnt == 0u) go = false;
+                    if (go && S.skip_dead_rays && ray_cannot_hit_triangles(lr.p, lr.d)) go = false;
                     if (!go) { rec++; return false; }
                     enter_mesh(lr.p, lr.d, linv, root_ref, root_cnt);
                     return true;
@@ -1679,6 +1699,7 @@ int upload_scene(const pth::SceneView& v, int32_t device, std::shared_ptr<std::v
     d.top_base = H.top_base; d.top_count = H.top_count;
     memcpy(d.env_color, H.env_color, sizeof(d.env_color)); d.env_map = H.env_map;
     // (the reference's default: `environment` is (0, 0, 0) unless the scene file says otherwise, scene.h:262; MI355PT_NO_BLACK_ENV: A/B and test switch)
+    d.skip_dead_rays = getenv("MI355PT_WALK_DEAD_RAYS") ? 0 : 1;
     d.env_black = (H.env_map < 0 && H.env_color[0] == 0.0f && H.env_color[1] == 0.0f && H.env_color[2] == 0.0f && n_li > 0 && !getenv("MI355PT_NO_BLACK_ENV")) ? 1 : 0;
     // Texture::Sample tap offsets (scene.h:169-175), host libm like the reference: the same 64 floats for every scene.  They live in
     // constant memory of the device (g_filter_taps, pt_shade.h), not in an array inside DScene: k_shade's TABLES instances change

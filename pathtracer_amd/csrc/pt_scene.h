@@ -83,6 +83,7 @@ struct DScene {
     const float4*   recs;       int num_recs;
     float env_color[3];         int env_map;
     int env_black;              // the environment is the constant (0, 0, 0) and the scene has lights: a miss changes nothing (k_shade)
+    int skip_dead_rays;         // a ray with a zero direction or a NaN component is not walked through a mesh (it cannot hit a triangle: mi355pt.hip, ray_cannot_hit_triangles)
 };
 
 }  // namespace ptd

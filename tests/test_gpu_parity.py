@@ -11,7 +11,7 @@ same seeded inputs.  Bars (north_star / SURVEY 8d):
 import numpy as np
 import pytest
 
-from pathtracer_amd import PathTracer, capi
+from pathtracer_amd import DeviceScene, PathTracer, capi
 from tests import common
 
 pytestmark = pytest.mark.gpu
@@ -815,4 +815,54 @@ def test_fused_connect_same_results(built, name, monkeypatch):
     assert np.array_equal(ma.view(np.uint32), mb.view(np.uint32)) and np.array_equal(ca, cb)
     assert sa["closest_rays"] == sb["closest_rays"] and sa["shadow_rays"] == sb["shadow_rays"] and sa["shadow_rays_traversed"] == sb["shadow_rays_traversed"]
     assert sa["shadow_rays_traversed"] > 0
+    p2.close_render()
+
+
+@pytest.mark.parametrize("name", ["teapot_cornell", "grid_small"])
+def test_dead_rays_skip_meshes_same_results(built, name, monkeypatch):
+    """A ray with a zero direction, or with a NaN in its origin or direction, cannot hit a triangle (d.n = 0 fails the parallel test of
+    model.h:236-240; a NaN distance is never better than the best so far, model.cpp:25-60), but no slab test rejects it
+    (bvh.h:88-129: -inf > -inf and NaN compares fall through): the reference visits every node of the mesh for it.  The product
+    skips the meshes for such a ray (DScene::skip_dead_rays; one wave walking the 10 M nodes of C4 alone costs 0.2 s, and such
+    rays do occur: tools/diag_nonfinite.py) and still tests the analytic objects, which a ray with one NaN component can hit.
+    Checked against the oracle's literal walk -- closest hits and LightVisTest -- and against the product's own literal walk
+    (MI355PT_WALK_DEAD_RAYS=1), for such rays in every pattern among ordinary ones."""
+    s, orc, pt, w, h = built(name)
+    rng = np.random.default_rng(41)
+    n = 6000
+    cam = np.asarray(s.camera.pos, dtype=np.float32)
+    o = (cam + rng.normal(0.0, 0.3, (n, 3))).astype(np.float32)
+    d = (np.asarray(s.camera.dir, dtype=np.float32) + rng.normal(0.0, 0.4, (n, 3))).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    pat = rng.integers(0, 12, n)                    # 0-3: ordinary rays; 4-9: NaNs; 10-11: zero directions
+    for k in range(n):
+        if pat[k] == 4: d[k, rng.integers(0, 3)] = np.nan
+        elif pat[k] == 5: o[k, rng.integers(0, 3)] = np.nan
+        elif pat[k] == 6: d[k, :] = np.nan
+        elif pat[k] == 7: o[k, :] = np.nan
+        elif pat[k] == 8: d[k, rng.integers(0, 3)] = np.nan; o[k, rng.integers(0, 3)] = np.nan
+        elif pat[k] == 9: d[k, rng.integers(0, 3)] = -np.nan
+        elif pat[k] == 10: d[k, :] = 0.0
+        elif pat[k] == 11: d[k, :] = (0.0, -0.0, 0.0); o[k, :] *= np.float32(1.0e8)
+    onode, omesh, oface, ot = orc.trace_rays(o, d)
+    nan_ray = pat >= 4
+    assert (onode[~nan_ray] >= 0).mean() > 0.3
+    assert (omesh[nan_ray] < 0).all(), "the oracle's literal walk finds no triangle for such a ray"
+
+    def same_hits(a):
+        node, mesh, face, t = a
+        tt = (t.view(np.uint32) == ot.view(np.uint32)) | (np.isnan(t) & np.isnan(ot)) | (node < 0)
+        return np.array_equal(node, onode) and np.array_equal(mesh, omesh) and np.array_equal(face[onode >= 0], oface[onode >= 0]) and tt.all()
+    assert same_hits(pt.trace_rays(o, d))
+    tmax = np.where(rng.random(n) < 0.3, np.float32(1.0e30), rng.uniform(0.1, 30.0, n).astype(np.float32)).astype(np.float32)
+    want = orc.light_vis(o, d, tmax, 0)
+    got = pt.trace_visibility(o, d, tmax, 0)
+    assert np.array_equal(got, want), f"{(got != want).sum()} visibility results differ"
+    monkeypatch.setenv("MI355PT_WALK_DEAD_RAYS", "1")
+    ds2 = DeviceScene(s)
+    monkeypatch.delenv("MI355PT_WALK_DEAD_RAYS")
+    p2 = PathTracer(ds2)
+    p2.Init(w, h)
+    assert same_hits(p2.trace_rays(o, d))
+    assert np.array_equal(p2.trace_visibility(o, d, tmax, 0), want)
     p2.close_render()

@@ -2,6 +2,7 @@
 # Round measurement on the GPU box: bench line, kernel-trace stats, the two HBM-traffic PMC passes and one SQ pass
 # (VALU utilisation / wait share / occupancy), for one workload.
 #   bash tools/gpu_measure.sh <tag> [workload c1..c5 = c4] [samples per step = 64] [triangles of c5] [phase all|bench|pmc]     (through gpurun, from the repo root)
+# The bench line is taken as the driver takes it (20 steps after 5 warm-up steps; BENCH_STEPS="--steps 4 --warmup 1" for a scene whose steps take seconds).
 # BENCH_ARGS in the environment is appended to the bench command lines (e.g. "--cpu-crop 128 128 --cpu-spp 1" for the 100 M-triangle soup);
 # the phases exist because five runs of a scene that takes 100 s to build do not fit one gpurun call.
 # Afterwards, here: tools/rocpd_summary.py + tools/pmc_traffic.py turn the databases into the files kept under profiles/.
@@ -14,7 +15,7 @@ export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-$PWD}
 case $wl in c1) dims="--width 512 --height 512";; c2) dims="--width 1920 --height 1080";; *) dims="";; esac
 if [ $phase != pmc ]; then
-timeout -k 10 900 python3 bench.py --workload $wl $dims --spp-per-step $spp --tris $tris $BENCH_ARGS > $out/bench.json 2> $out/bench.err || exit 1
+timeout -k 10 900 python3 bench.py --workload $wl $dims --spp-per-step $spp --tris $tris ${BENCH_STEPS:---steps 20 --warmup 5} $BENCH_ARGS > $out/bench.json 2> $out/bench.err || exit 1
 tail -c 1500 $out/bench.json; echo
 cd /tmp
 timeout -k 10 600 rocprofv3 --kernel-trace --stats -d $out/trace -o trace -- python3 $R/bench.py --workload $wl $dims --spp-per-step $spp --tris $tris --no-cpu-baseline --no-roofline > $out/trace.log 2>&1 || exit 2
