@@ -8,7 +8,7 @@ steps = int(sys.argv[1]) if len(sys.argv) > 1 else 30
 spp = int(sys.argv[2]) if len(sys.argv) > 2 else 64
 w, h = 3840, 2160
 scene, _ = bench.build_scene(argparse.Namespace(workload="c4", grid=[205, 204], tris=0, width=w, height=h, seed=0x5EED))
-pt = PathTracer(DeviceScene(scene), max_bounces=int(os.environ.get("STEP_BOUNCES", "30")))
+pt = PathTracer(DeviceScene(scene), max_bounces=int(os.environ.get("STEP_BOUNCES", "30")), sample_offset=int(os.environ.get("STEP_OFFSET", "0")), sample_stride=int(os.environ.get("STEP_STRIDE", "1")))
 pt.Init(w, h)
 events = int(os.environ.get("STEP_EVENTS", "0"))     # 2: HIP events around every stage (kernel time per stage beside the wall time)
 if events: pt.set_profiling(events, False)
